@@ -1,0 +1,484 @@
+// crt_api.cpp -- the C ABI declared in include/crt.h.  Host code only; all device work goes through
+// crt_kernels.h.  There is no CPU rendering path in this library: without a usable HIP device every render
+// entry point fails with CRT_ERR_NO_DEVICE / CRT_ERR_HIP.
+#include "../../include/crt.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "crt_bvh.h"
+#include "crt_kernels.h"
+
+using namespace crt;
+
+// ---------------------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------------------
+static thread_local std::string g_error;
+
+static int fail(int code, const std::string &msg)
+{
+    g_error = msg;
+    return code;
+}
+static int hip_fail(hipError_t e, const char *what)
+{
+    (void)hipGetLastError();
+    const int code = (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorNoBinaryForGpu || e == hipErrorInvalidDeviceFunction ||
+                      e == hipErrorSharedObjectInitFailed) ? CRT_ERR_NO_DEVICE : CRT_ERR_HIP;
+    return fail(code, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t e_ = (expr);                         \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr); \
+    } while (0)
+
+extern "C" const char *crt_last_error(void) { return g_error.c_str(); }
+extern "C" int crt_version(void) { return CRT_VERSION; }
+extern "C" void crt_free(void *p) { free(p); }
+
+// ---------------------------------------------------------------------------------------------------------
+// OBJ reader (replaces Assimp in LoadModel, model_loader.h:15-55)
+// ---------------------------------------------------------------------------------------------------------
+static bool parse_corner(const char *&p, long nv, long nn, long &vi, long &ni)
+{
+    while (*p == ' ' || *p == '\t') p++;
+    if (*p == 0 || *p == '\n' || *p == '\r' || *p == '#') return false;
+    char *end;
+    long v = strtol(p, &end, 10);
+    if (end == p) return false;
+    p = end;
+    long t = 0, n = 0;
+    bool has_n = false;
+    if (*p == '/') {
+        p++;
+        if (*p != '/') { t = strtol(p, &end, 10); p = end; }
+        if (*p == '/') { p++; n = strtol(p, &end, 10); has_n = end != p; p = end; }
+    }
+    (void)t;
+    vi = v > 0 ? v - 1 : nv + v;
+    ni = has_n ? (n > 0 ? n - 1 : nn + n) : -1;
+    return true;
+}
+
+extern "C" int crt_load_obj(const char *path, float **xyz_nrm, uint32_t *nverts, uint32_t **indices, uint32_t *ntris)
+{
+    if (!path || !xyz_nrm || !nverts || !indices || !ntris) return fail(CRT_ERR_INVALID, "crt_load_obj: null argument");
+    *xyz_nrm = nullptr; *indices = nullptr; *nverts = 0; *ntris = 0;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(CRT_ERR_IO, std::string("crt_load_obj: cannot open ") + path);
+    std::vector<float> pos, nrm;
+    std::vector<float> verts;         // 6 floats per joined vertex
+    std::vector<uint32_t> idx;
+    std::map<std::pair<long, long>, uint32_t> joined; // (v, vn) -> vertex, first use order
+    std::vector<char> line(1 << 16);
+    int rc = CRT_OK;
+    while (fgets(line.data(), (int)line.size(), f)) {
+        const char *p = line.data();
+        while (*p == ' ' || *p == '\t') p++;
+        if (p[0] == 'v' && (p[1] == ' ' || p[1] == '\t')) {
+            char *e;
+            p += 2;
+            for (int k = 0; k < 3; k++) { pos.push_back(strtof(p, &e)); p = e; }
+        } else if (p[0] == 'v' && p[1] == 'n' && (p[2] == ' ' || p[2] == '\t')) {
+            char *e;
+            p += 3;
+            for (int k = 0; k < 3; k++) { nrm.push_back(strtof(p, &e)); p = e; }
+        } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
+            p += 2;
+            std::vector<uint32_t> corner;
+            long vi, ni;
+            const long nv = (long)pos.size() / 3, nn = (long)nrm.size() / 3;
+            while (parse_corner(p, nv, nn, vi, ni)) {
+                if (vi < 0 || vi >= nv || ni >= nn) { rc = fail(CRT_ERR_IO, std::string("crt_load_obj: face index out of range in ") + path); break; }
+                auto key = std::make_pair(vi, ni);
+                auto it = joined.find(key);
+                if (it == joined.end()) {
+                    const uint32_t id = (uint32_t)(verts.size() / 6);
+                    for (int k = 0; k < 3; k++) verts.push_back(pos[3 * (size_t)vi + k]);
+                    for (int k = 0; k < 3; k++) verts.push_back(ni >= 0 ? nrm[3 * (size_t)ni + k] : 0.0f);
+                    it = joined.emplace(key, id).first;
+                }
+                corner.push_back(it->second);
+            }
+            if (rc != CRT_OK) break;
+            for (size_t k = 2; k < corner.size(); k++) { // aiProcess_Triangulate: fan
+                idx.push_back(corner[0]); idx.push_back(corner[k - 1]); idx.push_back(corner[k]);
+            }
+        }
+    }
+    fclose(f);
+    if (rc != CRT_OK) return rc;
+    if (idx.empty()) return fail(CRT_ERR_IO, std::string("crt_load_obj: no faces in ") + path);
+    *xyz_nrm = (float *)malloc(verts.size() * sizeof(float));
+    *indices = (uint32_t *)malloc(idx.size() * sizeof(uint32_t));
+    if (!*xyz_nrm || !*indices) { free(*xyz_nrm); free(*indices); *xyz_nrm = nullptr; *indices = nullptr; return fail(CRT_ERR_LIMIT, "crt_load_obj: out of memory"); }
+    memcpy(*xyz_nrm, verts.data(), verts.size() * sizeof(float));
+    memcpy(*indices, idx.data(), idx.size() * sizeof(uint32_t));
+    *nverts = (uint32_t)(verts.size() / 6);
+    *ntris = (uint32_t)(idx.size() / 3);
+    return CRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// scene
+// ---------------------------------------------------------------------------------------------------------
+struct crt_scene {
+    std::vector<HostTriangle> tris;
+    std::vector<HostSphere> spheres;
+    std::vector<Material> mats;
+    std::vector<Texture> texs;
+    // prepared (host: ranks + BVH) / committed (device buffers)
+    bool prepared = false;
+    bool committed = false;
+    int device = -1;
+    std::vector<uint32_t> rank;
+    FlatBvh bvh;
+    void *d_nodes = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_mats = nullptr, *d_texs = nullptr;
+    unsigned long long *d_counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    SceneView view{};
+    // staging for host-pointer renders (grow only)
+    float *d_stage_rgb = nullptr; size_t stage_rgb_floats = 0;
+    int *d_stage_ids = nullptr; size_t stage_ids = 0;
+
+    void release_device()
+    {
+        if (device >= 0) (void)hipSetDevice(device);
+        void *ptrs[] = { d_nodes, d_tris, d_spheres, d_mats, d_texs, d_counters, d_stage_rgb, d_stage_ids };
+        for (void *p : ptrs) if (p) (void)hipFree(p);
+        d_nodes = d_tris = d_spheres = d_mats = d_texs = nullptr; d_counters = nullptr; d_stage_rgb = nullptr; d_stage_ids = nullptr;
+        stage_rgb_floats = stage_ids = 0;
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        ev0 = ev1 = nullptr;
+        committed = false;
+    }
+};
+
+extern "C" crt_scene *crt_scene_create(void) { return new (std::nothrow) crt_scene(); }
+extern "C" void crt_scene_destroy(crt_scene *s)
+{
+    if (!s) return;
+    s->release_device();
+    delete s;
+}
+
+extern "C" int crt_scene_add_texture(crt_scene *s, int type, const float a[3], const float b[3], float scale, uint32_t *out_id)
+{
+    if (!s || !a) return fail(CRT_ERR_INVALID, "crt_scene_add_texture: null argument");
+    if (type != CRT_TEX_SOLID && type != CRT_TEX_CHECKER) return fail(CRT_ERR_INVALID, "crt_scene_add_texture: unknown type");
+    if (type == CRT_TEX_CHECKER && !b) return fail(CRT_ERR_INVALID, "crt_scene_add_texture: checker needs two colours");
+    Texture t{};
+    t.type = type == CRT_TEX_SOLID ? TEX_SOLID : TEX_CHECKER;
+    t.ar = a[0]; t.ag = a[1]; t.ab = a[2];
+    if (b) { t.br = b[0]; t.bg = b[1]; t.bb = b[2]; }
+    t.inv_scale = type == CRT_TEX_CHECKER ? 1.f / scale : 0.0f; // texture.h:26
+    s->texs.push_back(t);
+    if (out_id) *out_id = (uint32_t)s->texs.size() - 1;
+    s->committed = false; s->prepared = false;
+    return CRT_OK;
+}
+
+extern "C" int crt_scene_add_material(crt_scene *s, int type, const float rgb[3], float param, uint32_t texture_id, uint32_t *out_id)
+{
+    if (!s || !rgb) return fail(CRT_ERR_INVALID, "crt_scene_add_material: null argument");
+    if (type < CRT_MAT_LAMBERTIAN || type > CRT_MAT_DIELECTRIC) return fail(CRT_ERR_INVALID, "crt_scene_add_material: unknown type");
+    const bool textured = type == CRT_MAT_LAMBERTIAN || type == CRT_MAT_DIFFUSE_LIGHT;
+    if (textured && texture_id == UINT32_MAX) { // material.h:22,107: new SolidColor(color)
+        int rc = crt_scene_add_texture(s, CRT_TEX_SOLID, rgb, nullptr, 1.0f, &texture_id);
+        if (rc) return rc;
+    }
+    if (textured && texture_id >= s->texs.size()) return fail(CRT_ERR_INVALID, "crt_scene_add_material: texture id out of range");
+    Material m{};
+    m.type = type; m.r = rgb[0]; m.g = rgb[1]; m.b = rgb[2]; m.param = param; m.tex = textured ? (int)texture_id : 0;
+    s->mats.push_back(m);
+    if (out_id) *out_id = (uint32_t)s->mats.size() - 1;
+    s->committed = false; s->prepared = false;
+    return CRT_OK;
+}
+
+extern "C" int crt_scene_add_mesh(crt_scene *s, const float *xyz, uint32_t stride_floats, uint32_t nverts, const uint32_t *indices, uint32_t ntris,
+                                  uint32_t material_id)
+{
+    if (!s || !xyz || !indices) return fail(CRT_ERR_INVALID, "crt_scene_add_mesh: null argument");
+    if (stride_floats < 3) return fail(CRT_ERR_INVALID, "crt_scene_add_mesh: stride_floats < 3");
+    if (material_id >= s->mats.size()) return fail(CRT_ERR_INVALID, "crt_scene_add_mesh: material id out of range");
+    if ((uint64_t)s->tris.size() + ntris > (1u << 28)) return fail(CRT_ERR_LIMIT, "crt_scene_add_mesh: more than 2^28 triangles");
+    for (uint32_t t = 0; t < ntris; t++) // scene.h:134-136 bounds check, here an error instead of a silent skip
+        for (int k = 0; k < 3; k++)
+            if (indices[3 * (size_t)t + k] >= nverts) return fail(CRT_ERR_INVALID, "crt_scene_add_mesh: vertex index out of range");
+    s->tris.reserve(s->tris.size() + ntris);
+    for (uint32_t t = 0; t < ntris; t++) { // scene.h:128-144
+        const float *p0 = xyz + (size_t)indices[3 * (size_t)t] * stride_floats;
+        const float *p1 = xyz + (size_t)indices[3 * (size_t)t + 1] * stride_floats;
+        const float *p2 = xyz + (size_t)indices[3 * (size_t)t + 2] * stride_floats;
+        HostTriangle tri;
+        tri.a = mk3(p0[0], p0[1], p0[2]); tri.b = mk3(p1[0], p1[1], p1[2]); tri.c = mk3(p2[0], p2[1], p2[2]);
+        tri.material = (int)material_id;
+        s->tris.push_back(tri);
+    }
+    s->committed = false; s->prepared = false;
+    return CRT_OK;
+}
+
+extern "C" int crt_scene_add_sphere(crt_scene *s, const float center[3], float radius, uint32_t material_id)
+{
+    if (!s || !center) return fail(CRT_ERR_INVALID, "crt_scene_add_sphere: null argument");
+    if (material_id >= s->mats.size()) return fail(CRT_ERR_INVALID, "crt_scene_add_sphere: material id out of range");
+    HostSphere sp;
+    sp.center = mk3(center[0], center[1], center[2]);
+    sp.radius_arg = radius;
+    sp.radius = 0.0f > radius ? 0.0f : radius; // sphere.h:11 std::max(0.0f, radius)
+    sp.material = (int)material_id;
+    s->spheres.push_back(sp);
+    s->committed = false; s->prepared = false;
+    return CRT_OK;
+}
+
+static int get_env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+template <class T>
+static int upload(void **dst, const std::vector<T> &v)
+{
+    const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 64);
+    HIP_TRY(hipMalloc(dst, bytes));
+    if (!v.empty()) HIP_TRY(hipMemcpy(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return CRT_OK;
+}
+
+extern "C" int crt_scene_commit(crt_scene *s, int device)
+{
+    if (!s) return fail(CRT_ERR_INVALID, "crt_scene_commit: null scene");
+    if (s->tris.empty() && s->spheres.empty()) return fail(CRT_ERR_INVALID, "crt_scene_commit: empty scene");
+    if (s->spheres.size() > 4096) return fail(CRT_ERR_LIMIT, "crt_scene_commit: more than 4096 spheres (spheres are a flat list)");
+    s->release_device();
+    s->prepared = false;
+
+    // reference order: all triangles, then all spheres (scene.h:161-165)
+    std::vector<Box> boxes;
+    boxes.reserve(s->tris.size() + s->spheres.size());
+    for (const HostTriangle &t : s->tris) boxes.push_back(reference_triangle_box(t));
+    for (const HostSphere &sp : s->spheres) boxes.push_back(reference_sphere_box(sp));
+    Box scene_box;
+    reference_ranks(boxes, s->rank, scene_box);
+
+    const uint32_t max_leaf = (uint32_t)get_env_int("CRT_MAX_LEAF", 4);
+    build_bvh(s->tris, s->rank, max_leaf, s->bvh);
+    if (s->bvh.depth > CRT_STACK_DEPTH) return fail(CRT_ERR_LIMIT, "crt_scene_commit: BVH deeper than the traversal stack");
+
+    std::vector<Sphere> spheres(s->spheres.size());
+    for (size_t k = 0; k < s->spheres.size(); k++) {
+        Sphere &o = spheres[k];
+        o.cx = s->spheres[k].center.x; o.cy = s->spheres[k].center.y; o.cz = s->spheres[k].center.z; o.radius = s->spheres[k].radius;
+        o.id = (int)(s->tris.size() + k); o.rank = (int)s->rank[s->tris.size() + k]; o.mat = s->spheres[k].material; o.pad = 0;
+    }
+
+    s->prepared = true;
+    if (device == CRT_DEVICE_NONE) return CRT_OK; // host-side preparation only (ranks, BVH); rendering stays unavailable
+
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(CRT_ERR_NO_DEVICE, "crt_scene_commit: no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    s->device = device;
+    int rc;
+    if ((rc = upload(&s->d_nodes, s->bvh.nodes))) return rc;
+    if ((rc = upload(&s->d_tris, s->bvh.tris))) return rc;
+    if ((rc = upload(&s->d_spheres, spheres))) return rc;
+    if ((rc = upload(&s->d_mats, s->mats))) return rc;
+    if ((rc = upload(&s->d_texs, s->texs))) return rc;
+    HIP_TRY(hipMalloc((void **)&s->d_counters, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipEventCreate(&s->ev0));
+    HIP_TRY(hipEventCreate(&s->ev1));
+
+    SceneView &v = s->view;
+    v.nodes = (const q4 *)s->d_nodes; v.tris = (const q4 *)s->d_tris; v.spheres = (const Sphere *)s->d_spheres;
+    v.mats = (const Material *)s->d_mats; v.texs = (const Texture *)s->d_texs;
+    v.root_ref = s->bvh.root_ref; v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size();
+    v.root_min = s->bvh.root_box.mn; v.root_max = s->bvh.root_box.mx;
+    s->committed = true;
+    return CRT_OK;
+}
+
+extern "C" int crt_scene_get_info(const crt_scene *s, crt_scene_info *info)
+{
+    if (!s || !info) return fail(CRT_ERR_INVALID, "crt_scene_get_info: null argument");
+    if (!s->prepared) return fail(CRT_ERR_INVALID, "crt_scene_get_info: scene not committed");
+    memset(info, 0, sizeof *info);
+    info->num_triangles = (uint32_t)s->tris.size(); info->num_spheres = (uint32_t)s->spheres.size();
+    info->num_materials = (uint32_t)s->mats.size(); info->num_textures = (uint32_t)s->texs.size();
+    info->num_nodes = (uint32_t)(s->bvh.nodes.size() / 4); info->bvh_depth = s->bvh.depth; info->max_leaf_size = s->bvh.max_leaf;
+    info->device = s->committed ? (uint32_t)s->device : UINT32_MAX;
+    info->node_bytes = s->bvh.nodes.size() * sizeof(q4); info->triangle_bytes = s->bvh.tris.size() * sizeof(q4);
+    info->sphere_bytes = s->spheres.size() * sizeof(Sphere);
+    info->bounds_min[0] = s->bvh.root_box.mn.x; info->bounds_min[1] = s->bvh.root_box.mn.y; info->bounds_min[2] = s->bvh.root_box.mn.z;
+    info->bounds_max[0] = s->bvh.root_box.mx.x; info->bounds_max[1] = s->bvh.root_box.mx.y; info->bounds_max[2] = s->bvh.root_box.mx.z;
+    return CRT_OK;
+}
+
+extern "C" int crt_scene_get_ranks(const crt_scene *s, uint32_t *rank, uint32_t n)
+{
+    if (!s || !rank) return fail(CRT_ERR_INVALID, "crt_scene_get_ranks: null argument");
+    if (!s->prepared) return fail(CRT_ERR_INVALID, "crt_scene_get_ranks: scene not committed");
+    if (n != s->rank.size()) return fail(CRT_ERR_INVALID, "crt_scene_get_ranks: n != triangles + spheres");
+    memcpy(rank, s->rank.data(), n * sizeof(uint32_t));
+    return CRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// camera (camera.h:25-58): evaluated on the host, handed to the kernel by value
+// ---------------------------------------------------------------------------------------------------------
+static inline float degrees_to_radians(float degrees) { return (float)((double)degrees * 3.14159265358979323846 / (double)180.0f); } // utility.h:67-69
+
+extern "C" int crt_camera_init(crt_camera *cam, uint32_t width, const float lookfrom[3], const float lookat[3], const float vup_[3], float vfov,
+                               float aspect, float defocus_angle, float focus_dist)
+{
+    if (!cam || !lookfrom || !lookat || !vup_) return fail(CRT_ERR_INVALID, "crt_camera_init: null argument");
+    (void)aspect; // camera.h:27 uses the member default 16/9, not the argument (F12)
+    const float aspect_ratio = 16.0f / 9.0f;
+    uint32_t image_height = (uint32_t)((float)width / aspect_ratio);
+    image_height = image_height < 1 ? 1 : image_height;
+    const f3 look_from = mk3(lookfrom[0], lookfrom[1], lookfrom[2]), look_at = mk3(lookat[0], lookat[1], lookat[2]), vup = mk3(vup_[0], vup_[1], vup_[2]);
+    const float theta = degrees_to_radians(vfov);
+    const float h = std::tan(theta / 2.0f);
+    const float viewport_height = 2.0f * h * focus_dist;
+    const float viewport_width = viewport_height * ((float)width / (float)image_height);
+    const f3 w = normalize(look_from - look_at);
+    const f3 u = normalize(cross(vup, w));
+    const f3 v = cross(w, u);
+    const f3 viewport_horizontal = u * viewport_width;
+    const f3 viewport_vertical = (-v) * viewport_height;
+    const f3 pdu = div3(viewport_horizontal, (float)width);
+    const f3 pdv = div3(viewport_vertical, (float)image_height);
+    const f3 upper_left = ((look_from - w * focus_dist) - viewport_horizontal * 0.5f) - viewport_vertical * 0.5f;
+    const f3 pixel00 = upper_left + (pdu + pdv) * 0.5f;
+    const float defocus_radius = focus_dist * std::tan(degrees_to_radians(defocus_angle / 2.0f));
+    const f3 disk_u = u * defocus_radius, disk_v = v * defocus_radius;
+    cam->image_width = width; cam->image_height = image_height;
+    cam->defocus_angle = 0.6f; // the constructor parameter shadows the member: get_ray tests the default (camera.h:20,94)
+    cam->focus_distance = focus_dist;
+    auto put = [](float dst[3], f3 s) { dst[0] = s.x; dst[1] = s.y; dst[2] = s.z; };
+    put(cam->center, look_from); put(cam->pixel00, pixel00); put(cam->pixel_delta_u, pdu); put(cam->pixel_delta_v, pdv);
+    put(cam->u, u); put(cam->v, v); put(cam->w, w); put(cam->defocus_disk_u, disk_u); put(cam->defocus_disk_v, disk_v);
+    put(cam->background, mk3(0.0f, 0.0f, 0.0f)); // camera.h:23
+    return CRT_OK;
+}
+
+static_assert(sizeof(crt_camera) == sizeof(CameraPOD), "crt_camera and CameraPOD must have the same layout");
+
+// ---------------------------------------------------------------------------------------------------------
+// render
+// ---------------------------------------------------------------------------------------------------------
+static bool is_device_pointer(const void *p)
+{
+    hipPointerAttribute_t attr;
+    memset(&attr, 0, sizeof attr);
+    const hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged || attr.type == hipMemoryTypeUnified;
+}
+
+extern "C" uint64_t crt_compact_floats(uint32_t width, uint32_t height, uint32_t tile_ranks)
+{
+    if (tile_ranks == 0) return 0;
+    const uint64_t ntiles = (uint64_t)((width + 7u) / 8u) * ((height + 7u) / 8u);
+    return ((ntiles + tile_ranks - 1) / tile_ranks) * 64u * 3u;
+}
+
+extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_render_params *p, float *out_rgb, int32_t *out_ids, crt_stats *stats)
+{
+    crt_scene *s = const_cast<crt_scene *>(cs);
+    if (!s || !cam || !p || !out_rgb) return fail(CRT_ERR_INVALID, "crt_render: null argument");
+    if (!s->committed) return fail(s->prepared ? CRT_ERR_NO_DEVICE : CRT_ERR_INVALID, "crt_render: scene not committed to a HIP device");
+    if (p->width == 0 || p->height == 0 || p->spp == 0) return fail(CRT_ERR_INVALID, "crt_render: empty frame or zero samples");
+    if (p->tile_ranks == 0 || p->tile_rank >= p->tile_ranks) return fail(CRT_ERR_INVALID, "crt_render: tile_rank must be < tile_ranks");
+    if ((uint64_t)p->width * p->height > (1ull << 31)) return fail(CRT_ERR_LIMIT, "crt_render: more than 2^31 pixels");
+    HIP_TRY(hipSetDevice(s->device));
+    hipStream_t stream = (hipStream_t)p->stream;
+
+    RenderArgs ra{};
+    ra.width = p->width; ra.height = p->height; ra.tiles_x = (p->width + 7u) / 8u; ra.tiles_y = (p->height + 7u) / 8u;
+    ra.spp = p->spp; ra.sample_offset = p->sample_offset; ra.max_depth = p->max_depth; ra.ids_sample = p->ids_sample;
+    ra.tile_rank = p->tile_rank; ra.tile_ranks = p->tile_ranks;
+    ra.flags = ((p->flags & CRT_OUT_ACCUM) ? (uint32_t)RA_ACCUM : 0u) | ((p->flags & CRT_OUT_COMPACT) ? (uint32_t)RA_COMPACT : 0u);
+    ra.key0 = (uint32_t)p->seed; ra.key1 = (uint32_t)(p->seed >> 32);
+
+    const size_t npix = (size_t)p->width * p->height;
+    const size_t rgb_floats = (p->flags & CRT_OUT_COMPACT) ? (size_t)crt_compact_floats(p->width, p->height, p->tile_ranks) : npix * 3;
+    const bool rgb_on_device = is_device_pointer(out_rgb);
+    const bool ids_on_device = out_ids ? is_device_pointer(out_ids) : true;
+    float *d_rgb = out_rgb;
+    int *d_ids = out_ids;
+    if (!rgb_on_device) {
+        if (s->stage_rgb_floats < rgb_floats) {
+            if (s->d_stage_rgb) (void)hipFree(s->d_stage_rgb);
+            s->d_stage_rgb = nullptr; s->stage_rgb_floats = 0;
+            HIP_TRY(hipMalloc((void **)&s->d_stage_rgb, rgb_floats * sizeof(float)));
+            s->stage_rgb_floats = rgb_floats;
+        }
+        d_rgb = s->d_stage_rgb;
+        // a partial (tile_ranks > 1, row-major) render leaves other ranks' pixels untouched: start from the caller's content
+        if (p->tile_ranks > 1 && !(p->flags & CRT_OUT_COMPACT)) HIP_TRY(hipMemcpyAsync(d_rgb, out_rgb, rgb_floats * sizeof(float), hipMemcpyHostToDevice, stream));
+    }
+    if (out_ids && !ids_on_device) {
+        if (s->stage_ids < npix) {
+            if (s->d_stage_ids) (void)hipFree(s->d_stage_ids);
+            s->d_stage_ids = nullptr; s->stage_ids = 0;
+            HIP_TRY(hipMalloc((void **)&s->d_stage_ids, npix * sizeof(int)));
+            s->stage_ids = npix;
+        }
+        d_ids = s->d_stage_ids;
+        if (p->tile_ranks > 1) HIP_TRY(hipMemcpyAsync(d_ids, out_ids, npix * sizeof(int), hipMemcpyHostToDevice, stream));
+    }
+
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipEventRecord(s->ev0, stream));
+    HIP_TRY(launch_render(s->view, *reinterpret_cast<const CameraPOD *>(cam), ra, d_rgb, d_ids, s->d_counters, (p->flags & CRT_COUNT_WORK) != 0, stream));
+    HIP_TRY(hipEventRecord(s->ev1, stream));
+
+    if (!rgb_on_device) HIP_TRY(hipMemcpyAsync(out_rgb, d_rgb, rgb_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (out_ids && !ids_on_device) HIP_TRY(hipMemcpyAsync(out_ids, d_ids, npix * sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (stats) {
+        unsigned long long c[8];
+        HIP_TRY(hipMemcpyAsync(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        memset(stats, 0, sizeof *stats);
+        stats->rays = c[0]; stats->nodes = c[1]; stats->tri_tests = c[2]; stats->sphere_tests = c[3]; stats->tie_refolds = c[4];
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        stats->kernel_ms = ms;
+    } else if (!rgb_on_device || (out_ids && !ids_on_device)) {
+        HIP_TRY(hipStreamSynchronize(stream)); // host buffers must be complete on return
+    }
+    return CRT_OK;
+}
+
+extern "C" int crt_untile(const float *compact_all, uint32_t width, uint32_t height, uint32_t tile_ranks, float *out_rgb, int device, void *stream)
+{
+    if (!compact_all || !out_rgb || tile_ranks == 0 || width == 0 || height == 0) return fail(CRT_ERR_INVALID, "crt_untile: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(launch_untile(compact_all, width, height, tile_ranks, out_rgb, (hipStream_t)stream));
+    return CRT_OK;
+}
+
+extern "C" int crt_finalize(const float *accum, uint32_t width, uint32_t height, uint32_t total_spp, float *out_rgb, int device, void *stream)
+{
+    if (!accum || !out_rgb || total_spp == 0 || width == 0 || height == 0) return fail(CRT_ERR_INVALID, "crt_finalize: bad argument");
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(launch_finalize(accum, (size_t)width * height * 3, total_spp, out_rgb, (hipStream_t)stream));
+    return CRT_OK;
+}

@@ -1,0 +1,271 @@
+// crt_bvh.cpp -- see crt_bvh.h.  Host code; float arithmetic that feeds ranks is written exactly as the
+// reference evaluates it (no contraction: this file is built with -ffp-contract=off).
+#include "crt_bvh.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace crt {
+
+// ---------------------------------------------------------------------------------------------------------
+// Reference boxes and Morton ranks
+// ---------------------------------------------------------------------------------------------------------
+static inline float min3f(float a, float b, float c) { return fminf(fminf(fminf(a, a), b), c); } // utility.h:45-51
+static inline float max3f(float a, float b, float c) { return fmaxf(fmaxf(fmaxf(a, a), b), c); } // utility.h:53-59
+
+// aabb.h:12-16: per axis the smaller coordinate becomes the interval minimum
+static Box box_from_points(f3 p, f3 q)
+{
+    Box r;
+    if (p.x < q.x) { r.mn.x = p.x; r.mx.x = q.x; } else { r.mn.x = q.x; r.mx.x = p.x; }
+    if (p.y < q.y) { r.mn.y = p.y; r.mx.y = q.y; } else { r.mn.y = q.y; r.mx.y = p.y; }
+    if (p.z < q.z) { r.mn.z = p.z; r.mx.z = q.z; } else { r.mn.z = q.z; r.mx.z = p.z; }
+    return r;
+}
+
+Box reference_triangle_box(const HostTriangle &t)
+{
+    const float EPSILON = 1e-4f;
+    return box_from_points(mk3(min3f(t.a.x, t.b.x, t.c.x) - EPSILON, min3f(t.a.y, t.b.y, t.c.y) - EPSILON, min3f(t.a.z, t.b.z, t.c.z) - EPSILON),
+                           mk3(max3f(t.a.x, t.b.x, t.c.x) + EPSILON, max3f(t.a.y, t.b.y, t.c.y) + EPSILON, max3f(t.a.z, t.b.z, t.c.z) + EPSILON));
+}
+
+Box reference_sphere_box(const HostSphere &s)
+{
+    const f3 rvec = mk3(s.radius_arg, s.radius_arg, s.radius_arg);
+    return box_from_points(s.center - rvec, s.center + rvec);
+}
+
+// interval.h:11-14 applied per axis (aabb.h:17-21)
+static Box box_union(const Box &a, const Box &b)
+{
+    Box r;
+    r.mn.x = a.mn.x <= b.mn.x ? a.mn.x : b.mn.x; r.mx.x = a.mx.x >= b.mx.x ? a.mx.x : b.mx.x;
+    r.mn.y = a.mn.y <= b.mn.y ? a.mn.y : b.mn.y; r.mx.y = a.mx.y >= b.mx.y ? a.mx.y : b.mx.y;
+    r.mn.z = a.mn.z <= b.mn.z ? a.mn.z : b.mn.z; r.mx.z = a.mx.z >= b.mx.z ? a.mx.z : b.mx.z;
+    return r;
+}
+
+// bvh.h:13-20
+static inline uint32_t expand_bits(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+// bvh.h:24-33
+static inline uint32_t morton_3d(f3 p)
+{
+    const float x = fminf(fmaxf(p.x * 1024.0f, 0.0f), 1023.0f);
+    const float y = fminf(fmaxf(p.y * 1024.0f, 0.0f), 1023.0f);
+    const float z = fminf(fmaxf(p.z * 1024.0f, 0.0f), 1023.0f);
+    return expand_bits((uint32_t)x) * 4 + expand_bits((uint32_t)y) * 2 + expand_bits((uint32_t)z);
+}
+
+void reference_ranks(const std::vector<Box> &boxes, std::vector<uint32_t> &rank, Box &scene_box)
+{
+    const size_t n = boxes.size();
+    rank.assign(n, 0);
+    if (n == 0) return;
+    scene_box = boxes[0]; // scene.h:167-170
+    for (size_t i = 1; i < n; i++) scene_box = box_union(scene_box, boxes[i]);
+    const f3 extent = scene_box.mx - scene_box.mn;
+    std::vector<uint32_t> code(n), order(n);
+    for (size_t i = 0; i < n; i++) { // bvh.h:35-48
+        const f3 centroid = (boxes[i].mn + boxes[i].mx) * 0.5f; // aabb.h:38-40
+        const f3 rel = centroid - scene_box.mn;
+        code[i] = morton_3d(mk3(rel.x / extent.x, rel.y / extent.y, rel.z / extent.z));
+    }
+    std::iota(order.begin(), order.end(), 0u);
+    // thrust::sort_by_key on uint32 keys is an LSD radix sort, hence stable (scene.h:301)
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return code[a] < code[b]; });
+    for (size_t i = 0; i < n; i++) rank[order[i]] = (uint32_t)i;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SAH BVH
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct DBox {
+    double mn[3], mx[3];
+    void reset() { for (int k = 0; k < 3; k++) { mn[k] = 1e300; mx[k] = -1e300; } }
+    void grow(const DBox &o) { for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], o.mn[k]); mx[k] = std::max(mx[k], o.mx[k]); } }
+    void grow_pt(const double p[3]) { for (int k = 0; k < 3; k++) { mn[k] = std::min(mn[k], p[k]); mx[k] = std::max(mx[k], p[k]); } }
+    double area() const
+    {
+        const double dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        return (dx < 0) ? 0.0 : 2.0 * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct Ref { Box box; double c[3]; uint32_t tri; };
+
+struct Builder {
+    const std::vector<HostTriangle> &tris;
+    const std::vector<uint32_t> &rank;
+    uint32_t max_leaf;
+    std::vector<Ref> refs;
+    FlatBvh &out;
+    static constexpr int NBINS = 16;
+    static constexpr double NODE_COST = 1.0, TRI_COST = 1.3;
+
+    Builder(const std::vector<HostTriangle> &t, const std::vector<uint32_t> &r, uint32_t ml, FlatBvh &o) : tris(t), rank(r), max_leaf(ml), out(o) {}
+
+    static DBox to_d(const Box &b)
+    {
+        DBox d;
+        d.mn[0] = b.mn.x; d.mn[1] = b.mn.y; d.mn[2] = b.mn.z; d.mx[0] = b.mx.x; d.mx[1] = b.mx.y; d.mx[2] = b.mx.z;
+        return d;
+    }
+    static uint32_t levels_needed(size_t n, uint32_t max_leaf)
+    { // levels of nodes a median-split subtree over n triangles needs
+        uint32_t l = 1;
+        size_t cap = 2 * (size_t)max_leaf;
+        while (cap < n) { cap *= 2; l++; }
+        return l;
+    }
+
+    int make_leaf(size_t lo, size_t hi)
+    {
+        const uint32_t first = (uint32_t)(out.tris.size() / 3);
+        for (size_t i = lo; i < hi; i++) {
+            const HostTriangle &t = tris[refs[i].tri];
+            q4 a, b, c;
+            a.x = t.a.x; a.y = t.a.y; a.z = t.a.z; b.x = t.b.x; b.y = t.b.y; b.z = t.b.z; c.x = t.c.x; c.y = t.c.y; c.z = t.c.z;
+            const int id = (int)refs[i].tri, rk = (int)rank[refs[i].tri], mat = t.material;
+            std::memcpy(&a.w, &id, 4); std::memcpy(&b.w, &rk, 4); std::memcpy(&c.w, &mat, 4);
+            out.tris.push_back(a); out.tris.push_back(b); out.tris.push_back(c);
+        }
+        const uint32_t count = (uint32_t)(hi - lo);
+        out.max_leaf = std::max(out.max_leaf, count);
+        return ~(int)((first << 3) | (count - 1));
+    }
+
+    Box range_box(size_t lo, size_t hi) const
+    {
+        Box b = refs[lo].box;
+        for (size_t i = lo + 1; i < hi; i++) {
+            const Box &o = refs[i].box;
+            b.mn.x = fminf(b.mn.x, o.mn.x); b.mn.y = fminf(b.mn.y, o.mn.y); b.mn.z = fminf(b.mn.z, o.mn.z);
+            b.mx.x = fmaxf(b.mx.x, o.mx.x); b.mx.y = fmaxf(b.mx.y, o.mx.y); b.mx.z = fmaxf(b.mx.z, o.mx.z);
+        }
+        return b;
+    }
+
+    // returns the ref of the subtree over refs[lo, hi); `levels` = node levels still available
+    int build(size_t lo, size_t hi, uint32_t levels, uint32_t depth, Box &box_out)
+    {
+        box_out = range_box(lo, hi);
+        const size_t n = hi - lo;
+        if (n == 1 || (n <= max_leaf && levels == 0)) return make_leaf(lo, hi);
+
+        DBox cb; cb.reset();
+        for (size_t i = lo; i < hi; i++) cb.grow_pt(refs[i].c);
+        size_t mid = 0;
+        bool have_split = false;
+        const bool force_median = levels <= levels_needed(n, max_leaf);
+        if (!force_median) {
+            double best_cost = 1e300; int best_axis = -1, best_bin = -1;
+            for (int axis = 0; axis < 3; axis++) {
+                const double ext = cb.mx[axis] - cb.mn[axis];
+                if (!(ext > 0)) continue;
+                DBox bb[NBINS]; size_t bc[NBINS];
+                for (int k = 0; k < NBINS; k++) { bb[k].reset(); bc[k] = 0; }
+                const double scale = NBINS / ext;
+                for (size_t i = lo; i < hi; i++) {
+                    int k = (int)((refs[i].c[axis] - cb.mn[axis]) * scale);
+                    k = std::min(std::max(k, 0), NBINS - 1);
+                    bb[k].grow(to_d(refs[i].box)); bc[k]++;
+                }
+                double right_area[NBINS]; size_t right_cnt[NBINS];
+                DBox acc; acc.reset(); size_t cnt = 0;
+                for (int k = NBINS - 1; k > 0; k--) { acc.grow(bb[k]); cnt += bc[k]; right_area[k] = acc.area(); right_cnt[k] = cnt; }
+                acc.reset(); cnt = 0;
+                for (int k = 0; k < NBINS - 1; k++) {
+                    acc.grow(bb[k]); cnt += bc[k];
+                    if (cnt == 0 || right_cnt[k + 1] == 0) continue;
+                    const double cost = acc.area() * (double)cnt + right_area[k + 1] * (double)right_cnt[k + 1];
+                    if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = k; }
+                }
+            }
+            if (best_axis >= 0) {
+                const double parent_area = to_d(box_out).area();
+                const double split_cost = NODE_COST + TRI_COST * best_cost / std::max(parent_area, 1e-300);
+                const double leaf_cost = TRI_COST * (double)n;
+                if (n <= max_leaf && leaf_cost <= split_cost) return make_leaf(lo, hi);
+                const double ext = cb.mx[best_axis] - cb.mn[best_axis];
+                const double scale = NBINS / ext;
+                const double mn = cb.mn[best_axis];
+                auto it = std::partition(refs.begin() + (long)lo, refs.begin() + (long)hi, [&](const Ref &r) {
+                    int k = (int)((r.c[best_axis] - mn) * scale);
+                    k = std::min(std::max(k, 0), NBINS - 1);
+                    return k <= best_bin;
+                });
+                mid = (size_t)(it - refs.begin());
+                have_split = mid > lo && mid < hi;
+            } else if (n <= max_leaf) {
+                return make_leaf(lo, hi); // all centroids coincide
+            }
+        }
+        if (!have_split) { // object median along the widest centroid axis (also the depth-bounded fallback)
+            int axis = 0;
+            double w = -1;
+            for (int k = 0; k < 3; k++) if (cb.mx[k] - cb.mn[k] > w) { w = cb.mx[k] - cb.mn[k]; axis = k; }
+            mid = lo + n / 2;
+            std::nth_element(refs.begin() + (long)lo, refs.begin() + (long)mid, refs.begin() + (long)hi,
+                             [&](const Ref &a, const Ref &b) { return a.c[axis] < b.c[axis] || (a.c[axis] == b.c[axis] && a.tri < b.tri); });
+        }
+        const int node = (int)(out.nodes.size() / 4);
+        out.nodes.resize(out.nodes.size() + 4);
+        out.depth = std::max(out.depth, depth);
+        Box b0, b1;
+        const uint32_t next_levels = levels > 0 ? levels - 1 : 0;
+        const int r0 = build(lo, mid, next_levels, depth + 1, b0);
+        const int r1 = build(mid, hi, next_levels, depth + 1, b1);
+        q4 *q = &out.nodes[4 * (size_t)node];
+        q[0].x = b0.mn.x; q[0].y = b0.mn.y; q[0].z = b0.mn.z; std::memcpy(&q[0].w, &r0, 4);
+        q[1].x = b0.mx.x; q[1].y = b0.mx.y; q[1].z = b0.mx.z; std::memcpy(&q[1].w, &r1, 4);
+        q[2].x = b1.mn.x; q[2].y = b1.mn.y; q[2].z = b1.mn.z; q[2].w = 0.0f;
+        q[3].x = b1.mx.x; q[3].y = b1.mx.y; q[3].z = b1.mx.z; q[3].w = 0.0f;
+        return node;
+    }
+};
+
+} // namespace
+
+void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t> &rank, uint32_t max_leaf, FlatBvh &out)
+{
+    out = FlatBvh();
+    if (tris.empty()) return;
+    max_leaf = std::min(std::max(max_leaf, 1u), 8u);
+    // Rounding margin of the pruning slab test (crt_traverse.h): the ray origin is re-based to the root box, so
+    // plane times carry an absolute error of a few ulp of the largest coordinate; 2^-18 * max|coord| covers it
+    // with a factor > 4 to spare, on top of the reference's own 1e-4 padding.
+    float maxabs = 0.0f;
+    for (const HostTriangle &t : tris) {
+        const float v[9] = { t.a.x, t.a.y, t.a.z, t.b.x, t.b.y, t.b.z, t.c.x, t.c.y, t.c.z };
+        for (float f : v) maxabs = fmaxf(maxabs, fabsf(f));
+    }
+    const float margin = fmaxf(1e-5f, maxabs * 3.814697265625e-06f);
+    Builder b(tris, rank, max_leaf, out);
+    b.refs.resize(tris.size());
+    for (size_t i = 0; i < tris.size(); i++) {
+        Box bx = reference_triangle_box(tris[i]);
+        bx.mn = bx.mn - mk3(margin, margin, margin);
+        bx.mx = bx.mx + mk3(margin, margin, margin);
+        b.refs[i].box = bx;
+        b.refs[i].c[0] = 0.5 * ((double)bx.mn.x + bx.mx.x); b.refs[i].c[1] = 0.5 * ((double)bx.mn.y + bx.mx.y);
+        b.refs[i].c[2] = 0.5 * ((double)bx.mn.z + bx.mx.z);
+        b.refs[i].tri = (uint32_t)i;
+    }
+    out.nodes.reserve(4 * tris.size());
+    out.tris.reserve(3 * tris.size());
+    out.root_ref = b.build(0, tris.size(), CRT_STACK_DEPTH, 1, out.root_box);
+}
+
+} // namespace crt

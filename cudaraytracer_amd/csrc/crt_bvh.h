@@ -1,0 +1,41 @@
+// crt_bvh.h -- host-side scene preparation: reference primitive boxes / Morton ranks (the part of the
+// reference's setup that decides hot-path results) and this library's own SAH BVH, flattened to 64-byte
+// two-child nodes and 48-byte triangle slots.
+#pragma once
+
+#include <stdint.h>
+#include <vector>
+
+#include "crt_traverse.h"
+
+namespace crt {
+
+struct HostTriangle { f3 a, b, c; int material; };
+struct HostSphere { f3 center; float radius_arg; float radius; int material; }; // radius = max(0, radius_arg) (sphere.h:11)
+
+struct Box { f3 mn, mx; };
+
+// Triangle::init (triangle.h:28-46): min/max of the vertices -/+ 1e-4
+Box reference_triangle_box(const HostTriangle &t);
+// Sphere ctor (sphere.h:12-15): AABB(center - rvec, center + rvec) with the *unclamped* radius argument
+Box reference_sphere_box(const HostSphere &s);
+
+// rank[i] = position of primitive i (triangles, then spheres) in the reference's stable sort by 30-bit Morton
+// code of the box centroid normalised to the scene box (scene.h:167-170, bvh.h:13-48, scene.h:299-301).
+// This is the DFS leaf order of the reference LBVH (bvh.h:91-159), i.e. the order that decides ties.
+void reference_ranks(const std::vector<Box> &boxes, std::vector<uint32_t> &rank, Box &scene_box);
+
+struct FlatBvh {
+    std::vector<q4> nodes;   // 4 per node
+    std::vector<q4> tris;    // 3 per slot
+    int root_ref = CRT_BVH_NONE;
+    Box root_box{};
+    uint32_t depth = 0;      // levels of nodes on the longest root-to-leaf path
+    uint32_t max_leaf = 0;
+};
+
+// SAH (binned) BVH over the triangles' reference boxes, inflated by a rounding margin.  rank/ids are carried
+// into the triangle slots.  max_leaf in 1..8.
+void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t> &rank, uint32_t max_leaf, FlatBvh &out);
+
+} // namespace crt

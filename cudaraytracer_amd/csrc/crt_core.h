@@ -1,0 +1,300 @@
+// crt_core.h -- per-lane arithmetic of the path-tracing hot path (gfx950 device code; also compilable for the
+// host so tests can single-step it without a GPU -- see tests/hostsim/).
+//
+// Every float operation that reaches an output is spelled out here (explicit __builtin_fmaf, no compiler
+// contraction: build with -ffp-contract=off, IEEE-correct division and sqrt) so that the result is a pure
+// function of the inputs, independent of compiler and of lane/wave scheduling.  Reference citations are to
+// /root/reference/CudaRayTracer/.
+#pragma once
+
+#include <stdint.h>
+#include <float.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define CRT_HD __host__ __device__ __forceinline__
+#else
+#define CRT_HD inline
+#endif
+
+namespace crt {
+
+// ---------------------------------------------------------------------------------------------------------
+// vec3 (stands in for glm::vec3; glm is not used anywhere)
+// ---------------------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+
+CRT_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+CRT_HD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+CRT_HD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+CRT_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+CRT_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+CRT_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+CRT_HD f3 div3(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+CRT_HD float fma1(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// a + s*b, one fma per component
+CRT_HD f3 axpy(float s, f3 b, f3 a) { return mk3(fma1(s, b.x, a.x), fma1(s, b.y, a.y), fma1(s, b.z, a.z)); }
+// glm::dot order (x*x' + y*y') + z*z', contracted left to right
+CRT_HD float dot(f3 a, f3 b) { return fma1(a.z, b.z, fma1(a.y, b.y, a.x * b.x)); }
+// glm::cross, each difference of products as fma(p, q, -(r*s))
+CRT_HD f3 cross(f3 a, f3 b)
+{
+    return mk3(fma1(a.y, b.z, -(b.y * a.z)), fma1(a.z, b.x, -(b.z * a.x)), fma1(a.x, b.y, -(b.x * a.y)));
+}
+CRT_HD float length(f3 a) { return __builtin_sqrtf(dot(a, a)); }
+CRT_HD f3 normalize(f3 a) { return a * (1.0f / __builtin_sqrtf(dot(a, a))); } // glm: v * inversesqrt(dot(v,v))
+
+// ---------------------------------------------------------------------------------------------------------
+// Philox4x32-10, counter = (pixel, sample, stage, block), key = seed.  Replaces curand XORWOW
+// (renderer.h:26,45; utility.h:71-73) so that a (pixel, sample, bounce) triple names its random numbers.
+// stage 0 = camera ray, stage 1 + depth = scatter at bounce `depth`.
+// ---------------------------------------------------------------------------------------------------------
+struct u4 { uint32_t x, y, z, w; };
+
+CRT_HD uint32_t mulhi32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(a, b);
+#else
+    return (uint32_t)(((uint64_t)a * (uint64_t)b) >> 32);
+#endif
+}
+
+CRT_HD u4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#if defined(__clang__)
+#pragma unroll
+#endif
+    for (int r = 0; r < 10; r++) {
+        const uint32_t hi0 = mulhi32(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = mulhi32(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    u4 o; o.x = c0; o.y = c1; o.z = c2; o.w = c3;
+    return o;
+}
+// (0,1] on a 2^-24 grid: same range as curand_uniform (utility.h:71-73), exactly representable.
+CRT_HD float u01(uint32_t x) { return (float)((x >> 8) + 1u) * 5.9604644775390625e-08f; }
+
+// ---------------------------------------------------------------------------------------------------------
+// sin / cos for arguments in (0, 2*pi] (the only ones utility.h:91-95 produces): quadrant reduction with a
+// three-part pi/2 and degree-7 / degree-8 polynomials, every step an explicit fma.  <= 1.5 ulp.
+// ---------------------------------------------------------------------------------------------------------
+CRT_HD void sincos_02pi(float x, float &s, float &c)
+{
+    const float kf = __builtin_rintf(x * 0.636619772367581343f);
+    const int k = (int)kf;
+    float r = fma1(kf, -1.5707962512969971f, x);
+    r = fma1(kf, -7.5497894158615964e-08f, r);
+    r = fma1(kf, -5.3903029534742384e-15f, r);
+    const float r2 = r * r;
+    float ps = fma1(r2, 2.6083159809786593541503e-06f, -1.981069071916863322258e-04f);
+    ps = fma1(ps, r2, 8.333307858556509017944336e-03f);
+    ps = fma1(ps, r2, -1.666666567325592041015625e-01f);
+    const float sr = fma1(r * r2, ps, r);
+    float pc = fma1(r2, 2.443315711809948e-05f, -1.388731625493765e-03f);
+    pc = fma1(pc, r2, 4.166664568298827e-02f);
+    pc = fma1(pc, r2, -0.5f);
+    const float cr = fma1(r2, pc, 1.0f);
+    const float ss = (k & 1) ? cr : sr;
+    const float cc = (k & 1) ? sr : cr;
+    s = (k & 2) ? -ss : ss;
+    c = ((k + 1) & 2) ? -cc : cc;
+}
+
+#define CRT_PI_F 3.14159274101257324f  // (float)M_PI
+#define CRT_2PI_F 6.28318548202514648f // (float)(2.0 * M_PI)
+
+// utility.h:90-98 random_unit_vector: theta ~ U(0,pi], phi ~ U(0,2pi] -- not uniform on the sphere, kept (F13).
+// u_theta, u_phi are the two uniforms in draw order.
+CRT_HD f3 random_unit_vector(float u_theta, float u_phi)
+{
+    const float theta = fma1(u_theta, CRT_PI_F - 0.0f, 0.0f);
+    const float phi = fma1(u_phi, CRT_2PI_F - 0.0f, 0.0f);
+    float st, ct, sp, cp;
+    sincos_02pi(theta, st, ct);
+    sincos_02pi(phi, sp, cp);
+    return mk3(st * cp, st * sp, ct);
+}
+
+// utility.h:111-113
+CRT_HD f3 reflect(f3 v, f3 n) { const float k = 2.0f * dot(v, n); return axpy(-k, n, v); }
+
+// ---------------------------------------------------------------------------------------------------------
+// Intersection arithmetic.  Both tests return the reference's t for the primitive *as a function of the ray
+// and tmin only*; the caller folds candidates against closest_so_far (see crt_traverse.h for why that is
+// equivalent to hittable_list.h:47-51).
+// ---------------------------------------------------------------------------------------------------------
+// triangle.h:48-76 (Moller-Trumbore).  true -> t is a candidate with t >= tmin - 1e-7.
+CRT_HD bool triangle_t(f3 a, f3 b, f3 c, f3 o, f3 d, float tmin, float &t_out)
+{
+    const f3 edge_ab = b - a;
+    const f3 edge_ac = c - a;
+    const f3 pvec = cross(d, edge_ac);
+    const float det = dot(edge_ab, pvec);
+    const float epsilon = 1e-7f;
+    if (__builtin_fabsf(det) < epsilon) return false;
+    const float inv_det = 1.0f / det;
+    const f3 tvec = o - a;
+    const float u = dot(tvec, pvec) * inv_det;
+    if (u < -epsilon || u > 1.0f + epsilon) return false;
+    const f3 qvec = cross(tvec, edge_ab);
+    const float v = dot(d, qvec) * inv_det;
+    if (v < -epsilon || u + v > 1.0f + epsilon) return false;
+    const float t = dot(edge_ac, qvec) * inv_det;
+    if (t < tmin - epsilon) return false;
+    t_out = t;
+    return true;
+}
+// triangle.h:75: the upper half of the interval test, against the running closest_so_far
+CRT_HD bool triangle_accepts(float t, float closest) { return !(t > closest + 1e-7f); }
+
+// sphere.h:22-41.  The reference tries the near root, then the far root, each against [tmin, closest]; since
+// far >= near, the root it can return is the first one >= tmin, accepted iff <= closest (sphere_accepts).
+CRT_HD bool sphere_t(f3 center, float radius, f3 o, f3 d, float tmin, float &t_out)
+{
+    const f3 oc = center - o;
+    const float a = dot(d, d);
+    const float b = dot(d, oc);
+    const float c = fma1(-radius, radius, dot(oc, oc));
+    const float discriminant = fma1(b, b, -(a * c));
+    if (discriminant < 0) return false;
+    const float sd = __builtin_sqrtf(discriminant);
+    float root = (b - sd) / a;
+    if (!(root >= tmin)) {
+        root = (b + sd) / a;
+        if (!(root >= tmin)) return false;
+    }
+    t_out = root;
+    return true;
+}
+CRT_HD bool sphere_accepts(float t, float closest) { return t <= closest; }
+
+// ---------------------------------------------------------------------------------------------------------
+// Records shared by host builder and kernels
+// ---------------------------------------------------------------------------------------------------------
+struct Material { int type; float r, g, b; float param; int tex; int pad0, pad1; };               // 32 B
+struct Texture { int type; float ar, ag, ab; float br, bg, bb; float inv_scale; };                // 32 B
+struct Sphere { float cx, cy, cz, radius; int id; int rank; int mat; int pad; };                  // 32 B
+
+enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIFFUSE_LIGHT = 2, MAT_DIELECTRIC = 3 };
+enum { TEX_SOLID = 0, TEX_CHECKER = 1 };
+
+struct CameraPOD { // mirrors crt_camera (include/crt.h)
+    uint32_t image_width, image_height;
+    float defocus_angle, focus_distance;
+    f3 center, pixel00, pdu, pdv, u, v, w, disk_u, disk_v, background;
+};
+
+// texture.h:16, 31-39.  `a` is returned where the floor-sum is odd (the reference's `is_even` is true then).
+CRT_HD f3 texture_value(const Texture &t, f3 p)
+{
+    const f3 ca = mk3(t.ar, t.ag, t.ab);
+    if (t.type == TEX_SOLID) return ca;
+    const int xi = (int)__builtin_floorf(t.inv_scale * p.x);
+    const int yi = (int)__builtin_floorf(t.inv_scale * p.y);
+    const int zi = (int)__builtin_floorf(t.inv_scale * p.z);
+    const bool pick_a = ((xi + yi + zi) % 2) != 0;
+    return pick_a ? ca : mk3(t.br, t.bg, t.bb);
+}
+
+// hittable.h:18-21
+CRT_HD f3 face_normal(f3 d, f3 outward, bool &front_face)
+{
+    front_face = dot(d, outward) < 0.0f;
+    return front_face ? outward : -outward;
+}
+
+// utility.h:115-120
+CRT_HD f3 refract(f3 uv, f3 n, float etai_over_etat)
+{
+    const float cos_theta = __builtin_fminf(dot(-uv, n), 1.0f);
+    const f3 r_out_perp = axpy(cos_theta, n, uv) * etai_over_etat;
+    const float l = length(r_out_perp);
+    const f3 r_out_parallel = n * (-__builtin_sqrtf(__builtin_fabsf(fma1(-l, l, 1.0f))));
+    return r_out_perp + r_out_parallel;
+}
+// material.h:96-101, pow(x, 5) as ((x*x)*(x*x))*x
+CRT_HD float reflectance(float cosine, float ri)
+{
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 = r0 * r0;
+    const float x = 1.0f - cosine, x2 = x * x;
+    return fma1(1.0f - r0, (x2 * x2) * x, r0);
+}
+
+// material.h scatter().  rnd = first Philox block of stage 1+depth (x, y = theta, phi uniforms; the dielectric
+// uses x).  Returns false when the path ends (base Material / DiffuseLight, material.h:14-16).
+CRT_HD bool scatter(const Material &m, const Texture *texs, f3 ray_d, f3 point, f3 normal, bool front_face, u4 rnd,
+                    f3 &attenuation, f3 &new_o, f3 &new_d)
+{
+    if (m.type == MAT_LAMBERTIAN) { // material.h:24-34
+        f3 dir = normal + random_unit_vector(u01(rnd.x), u01(rnd.y));
+        if (length(dir) <= 1e-8f) dir = normal;
+        new_o = point; new_d = dir;
+        attenuation = texture_value(texs[m.tex], point);
+        return true;
+    }
+    if (m.type == MAT_METAL) { // material.h:44-51 (always scatters)
+        const f3 reflected = reflect(ray_d, normal);
+        new_d = axpy(m.param, random_unit_vector(u01(rnd.x), u01(rnd.y)), normalize(reflected));
+        new_o = point;
+        attenuation = mk3(m.r, m.g, m.b);
+        return true;
+    }
+    if (m.type == MAT_DIELECTRIC) { // material.h:61-91
+        attenuation = mk3(1.0f, 1.0f, 1.0f);
+        const float ri = front_face ? 1.0f / m.param : m.param;
+        const f3 unit_direction = normalize(ray_d);
+        const float cos_theta = __builtin_fminf(dot(-unit_direction, normal), 1.0f);
+        const float sin_theta = __builtin_sqrtf(fma1(-cos_theta, cos_theta, 1.0f));
+        const bool is_reflect = ri * sin_theta > 1.0f;
+        f3 direction;
+        if (is_reflect || reflectance(cos_theta, ri) > fma1(u01(rnd.x), 1.0f - 0.0f, 0.0f)) direction = reflect(unit_direction, normal);
+        else direction = refract(unit_direction, normal, ri);
+        new_o = axpy(1e-3f, direction, point);
+        new_d = direction;
+        return true;
+    }
+    return false;
+}
+// material.h:10-12, 109-111
+CRT_HD f3 emitted(const Material &m, const Texture *texs, f3 point)
+{
+    if (m.type == MAT_DIFFUSE_LIGHT) return texture_value(texs[m.tex], point);
+    return mk3(0.0f, 0.0f, 0.0f);
+}
+
+// camera.h:88-98 get_ray + 111-119.  Philox stage 0: block 0 = (square.x, square.y, disk0.x, disk0.y), block k>=1
+// = disk draws 2k-1 and 2k; utility.h:100-109 makes up to 10 rejection rounds and returns the 11th unconditionally.
+CRT_HD void camera_ray(const CameraPOD &cam, uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample, uint32_t k0, uint32_t k1,
+                       f3 &o, f3 &d)
+{
+    u4 r = philox4x32_10(pixel, sample, 0u, 0u, k0, k1);
+    const float ox = fma1(u01(r.x), 0.5f - -0.5f, -0.5f);
+    const float oy = fma1(u01(r.y), 0.5f - -0.5f, -0.5f);
+    const f3 pixel_center = axpy(oy + (float)j, cam.pdv, axpy(ox + (float)i, cam.pdu, cam.pixel00));
+    f3 origin = cam.center;
+    if (!(cam.defocus_angle <= 0.0f)) {
+        float px = fma1(u01(r.z), 1.0f - -1.0f, -1.0f);
+        float py = fma1(u01(r.w), 1.0f - -1.0f, -1.0f);
+        uint32_t draw = 0, block = 0;
+        // draws 0..9 are tested; draw 10 is taken as is
+        while (draw < 10 && !(__builtin_sqrtf(fma1(0.0f, 0.0f, fma1(py, py, px * px))) < 1.0f)) {
+            draw++;
+            if (draw & 1u) {
+                block++;
+                r = philox4x32_10(pixel, sample, 0u, block, k0, k1);
+                px = fma1(u01(r.x), 2.0f, -1.0f); py = fma1(u01(r.y), 2.0f, -1.0f);
+            } else {
+                px = fma1(u01(r.z), 2.0f, -1.0f); py = fma1(u01(r.w), 2.0f, -1.0f);
+            }
+        }
+        origin = axpy(py, cam.disk_v, axpy(px, cam.disk_u, cam.center));
+    }
+    o = origin;
+    d = pixel_center - origin;
+}
+
+} // namespace crt

@@ -1,0 +1,27 @@
+// crt_kernels.h -- launch interface between the C ABI (crt_api.cpp) and the gfx950 kernels (crt_kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "crt_traverse.h"
+
+namespace crt {
+
+enum { RA_ACCUM = 1u, RA_COMPACT = 2u };
+
+struct RenderArgs {
+    uint32_t width, height, tiles_x, tiles_y;
+    uint32_t spp, sample_offset, max_depth, ids_sample;
+    uint32_t tile_rank, tile_ranks, flags;
+    uint32_t key0, key1;
+};
+
+// counters: 8 x uint64 on the device: [0] rays [1] nodes [2] triangle tests [3] sphere tests [4] tie refolds
+hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,
+                         bool count_work, hipStream_t stream);
+hipError_t launch_untile(const float *compact_all, uint32_t width, uint32_t height, uint32_t tile_ranks, float *out, hipStream_t stream);
+hipError_t launch_finalize(const float *accum, size_t n, uint32_t total_spp, float *out, hipStream_t stream);
+
+} // namespace crt

@@ -1,0 +1,267 @@
+// crt_traverse.h -- closest-hit search over the 64-byte two-child BVH and the reference-order tie fold,
+// plus the per-sample path loop.  Per-lane code, templated on the stack storage (LDS columns on gfx950, a
+// plain array in the host single-stepper) and on the work counters.
+//
+// Why a different BVH and a different visit order still give the reference's answer
+// ---------------------------------------------------------------------------------
+// HittableList::hit (hittable_list.h:32-60) walks its LBVH depth-first, children[0] first, never culls by
+// distance (aabb.h:72-92 overwrites the interval it is given, F8) and lets a leaf replace the current hit
+// when  t <= closest + 1e-7  (triangle.h:75) or  t <= closest  (sphere.h:36, interval.h:19-21).  Its DFS leaf
+// order is the stable Morton order (bvh.h:120-157), called `rank` here.  So the reference result is a fold, in
+// rank order, over the primitives the ray actually hits, and each primitive's own t does not depend on
+// closest_so_far (crt_core.h: triangle_t, sphere_t).  Let t_min be the smallest candidate t and m the first
+// primitive in rank order that attains it: whatever happened before m, m is accepted when visited, and after m
+// only candidates within a few 1e-7 steps of t_min can be accepted.  Therefore:
+//   * if no other candidate lies within W = 1e-6 of t_min, the reference returns m            (fast path);
+//   * otherwise fold, in rank order, the candidates with t <= t_min + W with the reference's own
+//     comparisons                                                                             (tie path).
+// The fast path is an ordinary nearest-hit traversal (near child first, distance culling) that also raises a
+// flag whenever two candidates come within W of each other; the tie path re-walks the tree once per
+// candidate in the window, each time extracting the next rank, so it needs no storage.  It runs for a few
+// rays per million.  Box tests only prune: boxes contain the reference's own 1e-4-padded leaf boxes
+// (triangle.h:28-41) plus a margin that covers the rounding of the slab arithmetic below (crt_bvh.cpp).
+#pragma once
+
+#include "crt_core.h"
+
+namespace crt {
+
+struct alignas(16) q4 { float x, y, z, w; };
+
+CRT_HD int f2i(float f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_int(f);
+#else
+    union { float f; int i; } u; u.f = f; return u.i;
+#endif
+}
+
+// Node (4 x q4 = 64 B): [c0min.xyz, ref0] [c0max.xyz, ref1] [c1min.xyz, -] [c1max.xyz, -]
+// ref >= 0: index of a node; ref < 0: leaf, ~ref = (first_slot << 3) | (count - 1), count in 1..8.
+// Triangle slot (3 x q4 = 48 B): [a.xyz, prim id] [b.xyz, rank] [c.xyz, material]
+struct SceneView {
+    const q4 *nodes;
+    const q4 *tris;
+    const Sphere *spheres;
+    const Material *mats;
+    const Texture *texs;
+    int root_ref;        // BVH_NONE when there are no triangles
+    uint32_t ntris;      // triangle slots
+    uint32_t nspheres;
+    f3 root_min, root_max;
+};
+
+#define CRT_BVH_NONE 0x7FFFFFFF
+#define CRT_TIE_WINDOW 1e-6f
+#define CRT_STACK_DEPTH 32 // crt_bvh.cpp keeps the tree depth below this
+
+struct NoCounters {
+    CRT_HD void node() {}
+    CRT_HD void tri() {}
+    CRT_HD void sphere() {}
+    CRT_HD void ray() {}
+    CRT_HD void refold() {}
+};
+
+enum { MODE_CLOSEST = 0, MODE_NEXT_RANK = 1 };
+
+// State of one search.  code: triangle slot, or ntris + sphere index; -1 = nothing.
+struct Search {
+    float t;       // MODE_CLOSEST: smallest t so far.  MODE_NEXT_RANK: t of the candidate found
+    int code;
+    int rank;      // MODE_NEXT_RANK: rank of the candidate found (smallest rank > after_rank)
+    bool near_tie; // MODE_CLOSEST: two candidates within CRT_TIE_WINDOW of each other were seen
+};
+
+template <int MODE>
+CRT_HD void offer(Search &s, float t, int code, int rank, int after_rank, float t_hi)
+{
+    if (MODE == MODE_CLOSEST) {
+        if (s.code >= 0 && __builtin_fabsf(t - s.t) <= CRT_TIE_WINDOW) s.near_tie = true;
+        if (t < s.t) { s.t = t; s.code = code; }
+    } else {
+        if (t <= t_hi && rank > after_rank && rank < s.rank) { s.t = t; s.code = code; s.rank = rank; }
+    }
+}
+
+// One walk over spheres + BVH.  MODE_CLOSEST: s.t must start at tmax (FLT_MAX).  MODE_NEXT_RANK: only
+// candidates with t <= t_hi and rank > after_rank are considered, s.rank must start at INT_MAX.
+template <int MODE, class Stack, class Counters>
+CRT_HD void walk(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Stack &stack, Counters &cnt)
+{
+    // spheres: a short flat list (ground + light in the reference scenes, scene.h:164-165)
+    for (uint32_t k = 0; k < sc.nspheres; k++) {
+        const Sphere sp = sc.spheres[k];
+        float t;
+        cnt.sphere();
+        if (sphere_t(mk3(sp.cx, sp.cy, sp.cz), sp.radius, o, d, tmin, t)) offer<MODE>(s, t, (int)(sc.ntris + k), sp.rank, after_rank, t_hi);
+    }
+    if (sc.root_ref == CRT_BVH_NONE) return;
+
+    // slab arithmetic for pruning: idir finite, origin re-based to the root box entry so that rounding stays
+    // small against the box margin wherever the ray starts.
+    f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    if (!(__builtin_fabsf(idir.x) <= 1e30f)) idir.x = __builtin_copysignf(1e30f, d.x);
+    if (!(__builtin_fabsf(idir.y) <= 1e30f)) idir.y = __builtin_copysignf(1e30f, d.y);
+    if (!(__builtin_fabsf(idir.z) <= 1e30f)) idir.z = __builtin_copysignf(1e30f, d.z);
+    float shift;
+    {
+        const float ax = (sc.root_min.x - o.x) * idir.x, bx = (sc.root_max.x - o.x) * idir.x;
+        const float ay = (sc.root_min.y - o.y) * idir.y, by = (sc.root_max.y - o.y) * idir.y;
+        const float az = (sc.root_min.z - o.z) * idir.z, bz = (sc.root_max.z - o.z) * idir.z;
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+        const float hi = ((MODE == MODE_CLOSEST) ? s.t : t_hi) + CRT_TIE_WINDOW;
+        if (!(tn <= tf && tf >= 0.0f && tn <= hi)) return;
+        shift = __builtin_fmaxf(tn, 0.0f);
+    }
+    const f3 ob = axpy(shift, d, o);
+    const f3 ood = mk3(ob.x * idir.x, ob.y * idir.y, ob.z * idir.z);
+    const float lo = -shift; // t >= 0 in re-based time
+    // upper pruning bound in re-based time
+    float hi = ((MODE == MODE_CLOSEST) ? s.t : t_hi) - shift + CRT_TIE_WINDOW;
+
+    int cur = sc.root_ref;
+    stack.reset();
+    while (cur != CRT_BVH_NONE) {
+        while ((unsigned)cur < (unsigned)CRT_BVH_NONE) {
+            const q4 *n = sc.nodes + 4 * (size_t)cur;
+            const q4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+            cnt.node();
+            const float a0x = fma1(n0.x, idir.x, -ood.x), b0x = fma1(n1.x, idir.x, -ood.x);
+            const float a0y = fma1(n0.y, idir.y, -ood.y), b0y = fma1(n1.y, idir.y, -ood.y);
+            const float a0z = fma1(n0.z, idir.z, -ood.z), b0z = fma1(n1.z, idir.z, -ood.z);
+            const float a1x = fma1(n2.x, idir.x, -ood.x), b1x = fma1(n3.x, idir.x, -ood.x);
+            const float a1y = fma1(n2.y, idir.y, -ood.y), b1y = fma1(n3.y, idir.y, -ood.y);
+            const float a1z = fma1(n2.z, idir.z, -ood.z), b1z = fma1(n3.z, idir.z, -ood.z);
+            const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0x, b0x), __builtin_fminf(a0y, b0y)),
+                                              __builtin_fmaxf(__builtin_fminf(a0z, b0z), lo));
+            const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0x, b0x), __builtin_fmaxf(a0y, b0y)),
+                                              __builtin_fminf(__builtin_fmaxf(a0z, b0z), hi));
+            const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a1x, b1x), __builtin_fminf(a1y, b1y)),
+                                              __builtin_fmaxf(__builtin_fminf(a1z, b1z), lo));
+            const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a1x, b1x), __builtin_fmaxf(a1y, b1y)),
+                                              __builtin_fminf(__builtin_fmaxf(a1z, b1z), hi));
+            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+            const int r0 = f2i(n0.w), r1 = f2i(n1.w);
+            if (h0 && h1) {
+                const bool swap = tn1 < tn0;
+                stack.push(swap ? r0 : r1);
+                cur = swap ? r1 : r0;
+            } else if (h0) {
+                cur = r0;
+            } else if (h1) {
+                cur = r1;
+            } else {
+                cur = stack.pop();
+            }
+        }
+        if (cur < 0) {
+            const uint32_t bits = (uint32_t)~cur;
+            const uint32_t first = bits >> 3, count = (bits & 7u) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                const q4 *tp = sc.tris + 3 * (size_t)(first + k);
+                const q4 ta = tp[0], tb = tp[1], tc = tp[2];
+                float t;
+                cnt.tri();
+                if (triangle_t(mk3(ta.x, ta.y, ta.z), mk3(tb.x, tb.y, tb.z), mk3(tc.x, tc.y, tc.z), o, d, tmin, t)) {
+                    offer<MODE>(s, t, (int)(first + k), f2i(tb.w), after_rank, t_hi);
+                    if (MODE == MODE_CLOSEST) hi = s.t - shift + CRT_TIE_WINDOW;
+                }
+            }
+            cur = stack.pop();
+        }
+    }
+}
+
+// world->hit(ray, Interval(tmin, FLT_MAX), rec) (camera.h:68 -> hittable_list.h:17-63): returns the winning
+// primitive code (-1 = miss) and its t.
+template <class Stack, class Counters>
+CRT_HD int closest_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float &t_hit, Stack &stack, Counters &cnt)
+{
+    cnt.ray();
+    Search s;
+    s.t = tmax; s.code = -1; s.rank = 0; s.near_tie = false;
+    walk<MODE_CLOSEST>(sc, o, d, tmin, s, 0, 0.0f, stack, cnt);
+    if (s.code < 0) return -1;
+    // sphere.h:36 / triangle.h:75 also bound t by the caller's tmax (FLT_MAX everywhere in the reference)
+    if (!s.near_tie) { t_hit = s.t; return s.t <= tmax ? s.code : -1; }
+    // tie path: fold the window [t_min, t_min + W] in rank order with the reference's comparisons
+    cnt.refold();
+    const float t_hi = s.t + CRT_TIE_WINDOW;
+    float closest = tmax;
+    int win = -1, after = -1;
+    for (;;) {
+        Search n;
+        n.t = 0.0f; n.code = -1; n.rank = 0x7FFFFFFF; n.near_tie = false;
+        walk<MODE_NEXT_RANK>(sc, o, d, tmin, n, after, t_hi, stack, cnt);
+        if (n.code < 0) break;
+        const bool is_tri = (uint32_t)n.code < sc.ntris;
+        if (is_tri ? triangle_accepts(n.t, closest) : sphere_accepts(n.t, closest)) { closest = n.t; win = n.code; }
+        after = n.rank;
+    }
+    t_hit = closest;
+    return win;
+}
+
+// Hit record of the winning primitive: point, face-forward normal, material, primitive id
+// (triangle.h:78-83, sphere.h:43-47, hittable.h:18-21).
+struct Surface { f3 point, normal; bool front_face; int material; int prim; };
+
+CRT_HD Surface surface_at(const SceneView &sc, int code, f3 o, f3 d, float t)
+{
+    Surface r;
+    r.point = axpy(t, d, o);
+    if ((uint32_t)code < sc.ntris) {
+        const q4 *tp = sc.tris + 3 * (size_t)code;
+        const q4 ta = tp[0], tb = tp[1], tc = tp[2];
+        const f3 a = mk3(ta.x, ta.y, ta.z);
+        const f3 n = normalize(cross(mk3(tb.x, tb.y, tb.z) - a, mk3(tc.x, tc.y, tc.z) - a));
+        r.normal = face_normal(d, n, r.front_face);
+        r.material = f2i(tc.w);
+        r.prim = f2i(ta.w);
+    } else {
+        const Sphere sp = sc.spheres[(uint32_t)code - sc.ntris];
+        const f3 outward = div3(r.point - mk3(sp.cx, sp.cy, sp.cz), sp.radius);
+        r.normal = face_normal(d, outward, r.front_face);
+        r.material = sp.mat;
+        r.prim = sp.id;
+    }
+    return r;
+}
+
+// Camera::ray_color (camera.h:60-87) for sample `sample` of pixel (i, j); primary_prim receives the id of
+// the first hit (-1 = miss).
+template <class Stack, class Counters>
+CRT_HD f3 sample_radiance(const SceneView &sc, const CameraPOD &cam, uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample,
+                          uint32_t max_depth, uint32_t k0, uint32_t k1, Stack &stack, Counters &cnt, int &primary_prim)
+{
+    f3 o, d;
+    camera_ray(cam, i, j, pixel, sample, k0, k1, o, d);
+    f3 attenuation = mk3(1.0f, 1.0f, 1.0f);
+    f3 color = mk3(0.0f, 0.0f, 0.0f);
+    primary_prim = -1;
+    for (uint32_t depth = 0; depth < max_depth; depth++) {
+        float t;
+        const int code = closest_hit(sc, o, d, 0.001f, FLT_MAX, t, stack, cnt);
+        if (code < 0) {
+            color = mk3(fma1(attenuation.x, cam.background.x, color.x), fma1(attenuation.y, cam.background.y, color.y),
+                        fma1(attenuation.z, cam.background.z, color.z));
+            break;
+        }
+        const Surface sf = surface_at(sc, code, o, d, t);
+        if (depth == 0) primary_prim = sf.prim;
+        const Material m = sc.mats[sf.material];
+        const f3 e = emitted(m, sc.texs, sf.point);
+        color = mk3(fma1(attenuation.x, e.x, color.x), fma1(attenuation.y, e.y, color.y), fma1(attenuation.z, e.z, color.z));
+        const u4 rnd = philox4x32_10(pixel, sample, 1u + depth, 0u, k0, k1);
+        f3 att, no, nd;
+        if (!scatter(m, sc.texs, d, sf.point, sf.normal, sf.front_face, rnd, att, no, nd)) break;
+        attenuation = attenuation * att;
+        o = no; d = nd;
+    }
+    return color;
+}
+
+} // namespace crt

@@ -1,0 +1,155 @@
+/*
+ * crt.h -- C ABI of libcrt_hip.so: the MI355X (gfx950) path-tracing hot path behind the C++ surface of
+ * blueWhale903/CudaRayTracer (Scene / Renderer / Camera / LoadModel).
+ *
+ * Plain C: opaque handles, plain pointers and sizes, int return codes (0 = ok, non-zero = error, text via
+ * crt_last_error()).  Nothing here calls exit(): the reference's checkCudaErrors (utility.h:31-40) is
+ * process-fatal, this library reports and returns.  A handle is not thread-safe; different handles are.
+ * Every "reference:" note names the interface of /root/reference/CudaRayTracer/ that the entry point replaces.
+ */
+#ifndef CRT_H
+#define CRT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRT_VERSION 100
+
+/* ---- error convention -------------------------------------------------------------------------------- */
+enum {
+    CRT_OK = 0,
+    CRT_ERR_INVALID = 1,   /* bad argument / bad handle state          */
+    CRT_ERR_IO = 2,        /* file could not be read / parsed          */
+    CRT_ERR_HIP = 3,       /* a HIP runtime call failed                */
+    CRT_ERR_LIMIT = 4,     /* a documented size limit was exceeded     */
+    CRT_ERR_NO_DEVICE = 5  /* no gfx950 device / kernels not loadable  */
+};
+/* reference: check_cuda() message (utility.h:32-40); here a thread-local string, never exit(99). */
+const char *crt_last_error(void);
+int crt_version(void);
+
+/* ---- model loading ------------------------------------------------------------------------------------ */
+/* reference: bool LoadModel(path, std::vector<Vertex>&, std::vector<uint32_t>&) (model_loader.h:15-55),
+ * struct Vertex { vec3 position; vec3 normal; } (model_loader.h:10-13).  Own OBJ reader (v / vn / f, faces
+ * fan-triangulated, vertices joined on identical (v, vn) pairs in first-use order like
+ * aiProcess_JoinIdenticalVertices) instead of Assimp.  Outputs are malloc'ed; release with crt_free().
+ *   *xyz_nrm : nverts * 6 floats (position.xyz, normal.xyz) -- the Vertex array
+ *   *indices : ntris * 3 uint32 */
+int crt_load_obj(const char *path, float **xyz_nrm, uint32_t *nverts, uint32_t **indices, uint32_t *ntris);
+void crt_free(void *p);
+
+/* ---- scene -------------------------------------------------------------------------------------------- */
+/* reference: class Scene (scene.h:20-51) whose launch_*_scene() writes a device HittableList into
+ * Hittable** d_world (scene.h:158-177, 237-308); here an opaque handle that owns host staging + device SoA. */
+typedef struct crt_scene crt_scene;
+
+enum { CRT_TEX_SOLID = 0, CRT_TEX_CHECKER = 1 };                                   /* texture.h:12-44 */
+enum { CRT_MAT_LAMBERTIAN = 0, CRT_MAT_METAL = 1, CRT_MAT_DIFFUSE_LIGHT = 2, CRT_MAT_DIELECTRIC = 3 }; /* material.h */
+
+crt_scene *crt_scene_create(void);
+void crt_scene_destroy(crt_scene *s); /* reference: free_world<<<1,1>>> (kernel.cu:25-28) */
+
+/* reference: SolidColor(albedo) (texture.h:14), CheckerTexture(scale, c1, c2) (texture.h:28-29).
+ * CHECKER: `a` is the reference's first ("even") colour, returned where floor-sum is ODD (texture.h:36-38). */
+int crt_scene_add_texture(crt_scene *s, int type, const float a[3], const float b[3], float scale, uint32_t *out_id);
+/* reference: Lambertian(color|Texture*) (material.h:22-23), Metal(color, fuzz) (material.h:42),
+ * DiffuseLight(color|Texture*) (material.h:106-107), Dielectric(ior) (material.h:59).
+ * texture_id = UINT32_MAX: build a SolidColor from rgb.  param = fuzz (METAL) / refraction index (DIELECTRIC). */
+int crt_scene_add_material(crt_scene *s, int type, const float rgb[3], float param, uint32_t texture_id, uint32_t *out_id);
+/* reference: load_triangles<<<>>> (scene.h:92-155): one Triangle per index triple, Triangle::init() box.
+ * xyz has `stride_floats` floats per vertex (3 for packed positions, 6 for the Vertex array above). */
+int crt_scene_add_mesh(crt_scene *s, const float *xyz, uint32_t stride_floats, uint32_t nverts, const uint32_t *indices,
+                       uint32_t ntris, uint32_t material_id);
+/* reference: new Sphere(center, radius, material) (scene.h:59-82,164-165; sphere.h:10-16). */
+int crt_scene_add_sphere(crt_scene *s, const float center[3], float radius, uint32_t material_id);
+/* reference: kernel_triangles_scene + assign_morton_codes + thrust::sort_by_key + build_bvh (scene.h:280-307).
+ * Orders primitives like the reference (all triangles, then all spheres), computes each primitive's rank in
+ * the reference's stable Morton order (that order decides ties, hittable_list.h:47-59), builds this library's
+ * own SAH BVH (64-byte two-child nodes) and uploads everything to HIP device `device`. */
+#define CRT_DEVICE_NONE (-1) /* prepare on the host only (ranks, BVH, crt_scene_get_*); crt_render then fails with CRT_ERR_NO_DEVICE */
+int crt_scene_commit(crt_scene *s, int device);
+
+typedef struct crt_scene_info {
+    uint32_t num_triangles, num_spheres, num_materials, num_textures;
+    uint32_t num_nodes;      /* 64-byte two-child nodes          */
+    uint32_t bvh_depth;      /* deepest leaf (root = depth 1)    */
+    uint32_t max_leaf_size;
+    uint32_t device;         /* UINT32_MAX when prepared with CRT_DEVICE_NONE */
+    uint64_t node_bytes, triangle_bytes, sphere_bytes; /* resident HBM footprint */
+    float bounds_min[3], bounds_max[3];                /* triangle BVH root box  */
+} crt_scene_info;
+int crt_scene_get_info(const crt_scene *s, crt_scene_info *info);
+/* rank[i] = position of primitive i (triangles first, then spheres) in the reference's sorted Morton order
+ * (bvh.h:35-48 + scene.h:299-301).  n must equal num_triangles + num_spheres. */
+int crt_scene_get_ranks(const crt_scene *s, uint32_t *rank, uint32_t n);
+
+/* ---- camera ------------------------------------------------------------------------------------------- */
+/* reference: class Camera (camera.h:11-58, 100-109).  POD image of the constructed object, passed to the
+ * kernel by value.  Constructor quirks are kept: `aspect` is ignored (height = width / (16/9)), the vfov /
+ * vup / defocus_angle parameters shadow the members (camera.h:13,25-28,55). */
+typedef struct crt_camera {
+    uint32_t image_width, image_height;
+    float defocus_angle, focus_distance;
+    float center[3], pixel00[3], pixel_delta_u[3], pixel_delta_v[3];
+    float u[3], v[3], w[3], defocus_disk_u[3], defocus_disk_v[3], background[3];
+} crt_camera;
+int crt_camera_init(crt_camera *cam, uint32_t width, const float lookfrom[3], const float lookat[3], const float vup[3],
+                    float vfov, float aspect, float defocus_angle, float focus_dist);
+
+/* ---- render ------------------------------------------------------------------------------------------- */
+enum {
+    CRT_OUT_ACCUM = 1u,     /* out_rgb receives raw per-pixel sums (no /spp, no gamma): sample-split mode   */
+    CRT_OUT_COMPACT = 2u,   /* out_rgb is this rank's tiles only, tile-major (see crt_untile): tile mode    */
+    CRT_COUNT_WORK = 4u     /* also count node fetches / primitive tests (instrumented kernel, slower)      */
+};
+#define CRT_TILE 8u         /* tiles are 8x8 pixels = one wave64 (reference block shape, kernel.cu:50-51)   */
+
+typedef struct crt_render_params {
+    uint32_t width, height;       /* frame size (reference: Renderer ctor, renderer.h:48)                   */
+    uint32_t spp;                 /* samples rendered by this call                                          */
+    uint32_t sample_offset;       /* index of the first sample (Philox counter word 1)                      */
+    uint32_t max_depth;           /* reference literal 10 (camera.h:66)                                     */
+    uint32_t tile_rank, tile_ranks; /* render 8x8 tiles k (row-major) with k % tile_ranks == tile_rank      */
+    uint32_t flags;
+    uint32_t ids_sample;          /* which sample's primary-hit ids go to out_ids                           */
+    uint32_t reserved;
+    uint64_t seed;                /* Philox key; reference seed literal 1984 (renderer.h:45)                */
+    void *stream;                 /* hipStream_t, NULL = default stream                                     */
+} crt_render_params;
+
+typedef struct crt_stats {
+    uint64_t rays;          /* path segments traced = world->hit() calls (camera.h:68)                      */
+    uint64_t nodes;         /* 64-byte nodes fetched            (CRT_COUNT_WORK)                            */
+    uint64_t tri_tests;     /* 48-byte triangle records tested  (CRT_COUNT_WORK)                            */
+    uint64_t sphere_tests;  /* 32-byte sphere records tested    (CRT_COUNT_WORK)                            */
+    uint64_t tie_refolds;   /* rays that took the exact reference-order tie fold                            */
+    float kernel_ms;        /* hipEvent time of the render kernel on `stream`                               */
+    uint32_t reserved;
+} crt_stats;
+
+/* reference: Renderer::launch_kernel_render(vec3* framebuffer, Camera**, Hittable**) -> kernel_render
+ * (renderer.h:18-38, 64-73).  out_rgb: width*height*3 floats row-major, row 0 = top (or the compact tile list
+ * with CRT_OUT_COMPACT); out_ids (nullable): width*height int32 primary-hit primitive ids of sample
+ * `ids_sample` (-1 = miss).  Both may be device pointers (any HIP allocation on the scene's device) or host
+ * pointers (staged through an internal device buffer).  With stats != NULL the call synchronises `stream`
+ * before returning; with stats == NULL and device pointers it is asynchronous on `stream`. */
+int crt_render(const crt_scene *s, const crt_camera *cam, const crt_render_params *p, float *out_rgb, int32_t *out_ids,
+               crt_stats *stats);
+
+/* number of floats of a CRT_OUT_COMPACT buffer for one rank: ceil(ntiles / tile_ranks) * 64 * 3 (same for every rank) */
+uint64_t crt_compact_floats(uint32_t width, uint32_t height, uint32_t tile_ranks);
+/* Tile mode gather epilogue: `compact_all` holds the tile_ranks compact buffers back to back (rank-major, as an
+ * all-gather leaves them); writes the row-major frame.  Device pointers, asynchronous on `stream`.
+ * (new; the reference is single-GPU.) */
+int crt_untile(const float *compact_all, uint32_t width, uint32_t height, uint32_t tile_ranks, float *out_rgb, int device, void *stream);
+/* Sample mode reduce epilogue: accum (sum over `total_spp` samples) -> accum/total_spp -> gamma
+ * (renderer.h:36-37, color.h:5-24).  Device pointers, in place allowed, asynchronous on `stream`. */
+int crt_finalize(const float *accum, uint32_t width, uint32_t height, uint32_t total_spp, float *out_rgb, int device, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRT_H */

@@ -1,0 +1,205 @@
+"""ctypes binding of liboracle_crt.so (oracle/crt_ref.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, by __graft_entry__.smoke() and by the cpu_baseline leg of bench.py --
+never by the cudaraytracer_amd package.  Takes the same scene descriptions (cudaraytracer_amd.scenes) as the product.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle_crt.so")
+
+TRAVERSE_BVH, TRAVERSE_BRUTE_LEAF_ORDER, TRAVERSE_BRUTE_LIST_ORDER = 0, 1, 2
+
+
+class RefStats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("box_tests", C.c_uint64), ("tri_tests", C.c_uint64), ("sphere_tests", C.c_uint64)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("liboracle_crt.so not built: run `make -C oracle`")
+    L = C.CDLL(LIB_PATH)
+    fp = C.POINTER(C.c_float)
+    L.ref_philox4x32_10.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.ref_u01.argtypes = [C.c_uint32]
+    L.ref_u01.restype = C.c_float
+    L.ref_sincos.argtypes = [C.c_float, fp, fp]
+    L.ref_slab_test.argtypes = [fp, fp, fp, fp]
+    L.ref_triangle_hit.argtypes = [fp, fp, fp, fp, fp, C.c_float, C.c_float, fp, fp, C.POINTER(C.c_int)]
+    L.ref_sphere_hit.argtypes = [fp, C.c_float, fp, fp, C.c_float, C.c_float, fp, fp, C.POINTER(C.c_int)]
+    L.ref_morton_3d.argtypes = [C.c_float, C.c_float, C.c_float]
+    L.ref_morton_3d.restype = C.c_uint32
+    L.ref_scene_create.restype = C.c_void_p
+    L.ref_scene_destroy.argtypes = [C.c_void_p]
+    L.ref_scene_destroy.restype = None
+    L.ref_scene_add_texture.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_float]
+    L.ref_scene_add_material.argtypes = [C.c_void_p, C.c_int, fp, C.c_float, C.c_int]
+    L.ref_scene_add_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int]
+    L.ref_scene_add_sphere.argtypes = [C.c_void_p, fp, C.c_float, C.c_int]
+    L.ref_scene_commit.argtypes = [C.c_void_p]
+    L.ref_scene_size.argtypes = [C.c_void_p]
+    L.ref_scene_size.restype = C.c_uint32
+    L.ref_scene_build_stack_depth.argtypes = [C.c_void_p]
+    L.ref_scene_get_ranks.argtypes = [C.c_void_p, C.c_void_p]
+    L.ref_scene_get_ranks.restype = None
+    L.ref_scene_get_mortons.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ref_scene_get_mortons.restype = None
+    L.ref_scene_get_bbox.argtypes = [C.c_void_p, fp]
+    L.ref_scene_get_bbox.restype = None
+    L.ref_scene_get_prim_bbox.argtypes = [C.c_void_p, C.c_uint32, fp]
+    L.ref_scene_get_prim_bbox.restype = None
+    L.ref_scene_trace.argtypes = [C.c_void_p, fp, fp, C.c_float, C.c_float, C.c_int, fp]
+    L.ref_camera_init.argtypes = [C.c_void_p, C.c_uint32, fp, fp, fp, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.ref_camera_init.restype = None
+    L.ref_render.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint32,
+                             C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                             C.POINTER(RefStats)]
+    L.ref_camera_get_ray.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, fp, fp]
+    L.ref_camera_get_ray.restype = None
+    L.ref_random_unit_vector.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, fp]
+    L.ref_random_unit_vector.restype = None
+    L.ref_sizeof_camera.restype = C.c_uint32
+    _lib = L
+    return L
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    o = (C.c_uint32 * 4)()
+    lib().ref_philox4x32_10(c, k, o)
+    return list(o)
+
+
+def sincos(x):
+    s, c = C.c_float(), C.c_float()
+    lib().ref_sincos(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def slab_test(bmin, bmax, o, d):
+    return bool(lib().ref_slab_test(_f3(bmin), _f3(bmax), _f3(o), _f3(d)))
+
+
+def triangle_hit(a, b, c, o, d, tmin=0.001, tmax=3.4028234663852886e38):
+    t, n, f = C.c_float(), (C.c_float * 3)(), C.c_int()
+    if not lib().ref_triangle_hit(_f3(a), _f3(b), _f3(c), _f3(o), _f3(d), tmin, tmax, C.byref(t), n, C.byref(f)):
+        return None
+    return t.value, tuple(n), bool(f.value)
+
+
+def sphere_hit(center, radius, o, d, tmin=0.001, tmax=3.4028234663852886e38):
+    t, n, f = C.c_float(), (C.c_float * 3)(), C.c_int()
+    if not lib().ref_sphere_hit(_f3(center), radius, _f3(o), _f3(d), tmin, tmax, C.byref(t), n, C.byref(f)):
+        return None
+    return t.value, tuple(n), bool(f.value)
+
+
+class RefCamera:
+    def __init__(self, width, lookfrom, lookat, vup, vfov, aspect, defocus_angle, focus_dist):
+        L = lib()
+        self.buf = C.create_string_buffer(L.ref_sizeof_camera())
+        L.ref_camera_init(self.buf, width, _f3(lookfrom), _f3(lookat), _f3(vup), vfov, aspect, defocus_angle, focus_dist)
+
+    def raw(self):
+        return np.frombuffer(self.buf.raw, dtype=np.uint8).copy()
+
+    def get_ray(self, W, i, j, sample, seed):
+        o, d = (C.c_float * 3)(), (C.c_float * 3)()
+        lib().ref_camera_get_ray(self.buf, W, i, j, sample, seed, o, d)
+        return np.array(o, dtype=np.float32), np.array(d, dtype=np.float32)
+
+
+def make_camera(params, width):
+    """params: the dict returned by cudaraytracer_amd.scenes.make_camera."""
+    return RefCamera(width, params["lookfrom"], params["lookat"], params["vup"], params["vfov"], params["aspect"], params["defocus_angle"],
+                     params["focus_dist"])
+
+
+class RefScene:
+    def __init__(self, desc):
+        L = lib()
+        self._h = L.ref_scene_create()
+        for t in desc["textures"]:
+            L.ref_scene_add_texture(self._h, t["type"], _f3(t["a"]), _f3(t["b"]) if t.get("b") is not None else None, t.get("scale", 1.0))
+        for m in desc["materials"]:
+            L.ref_scene_add_material(self._h, m["type"], _f3(m["rgb"]), m["param"], -1 if m["texture"] is None else m["texture"])
+        for me in desc["meshes"]:
+            v = np.ascontiguousarray(me["vertices"], dtype=np.float32)
+            i = np.ascontiguousarray(me["indices"], dtype=np.uint32)
+            assert v.shape[1] == 3
+            if L.ref_scene_add_mesh(self._h, v.ctypes.data, v.shape[0], i.ctypes.data, i.shape[0], me["material"]) != 0:
+                raise ValueError("oracle: vertex index out of range")
+        for sp in desc["spheres"]:
+            L.ref_scene_add_sphere(self._h, _f3(sp["center"]), sp["radius"], sp["material"])
+        rc = L.ref_scene_commit(self._h)
+        if rc != 0:
+            raise RuntimeError("oracle: ref_scene_commit failed (%d)" % rc)
+        self.size = L.ref_scene_size(self._h)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().ref_scene_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def ranks(self):
+        out = np.empty(self.size, dtype=np.uint32)
+        lib().ref_scene_get_ranks(self._h, out.ctypes.data)
+        return out
+
+    def mortons(self):
+        codes = np.empty(self.size, dtype=np.uint32)
+        idx = np.empty(self.size, dtype=np.uint32)
+        lib().ref_scene_get_mortons(self._h, codes.ctypes.data, idx.ctypes.data)
+        return codes, idx
+
+    def bbox(self):
+        out = (C.c_float * 6)()
+        lib().ref_scene_get_bbox(self._h, out)
+        return np.array(out, dtype=np.float32)
+
+    def prim_bbox(self, i):
+        out = (C.c_float * 6)()
+        lib().ref_scene_get_prim_bbox(self._h, i, out)
+        return np.array(out, dtype=np.float32)
+
+    def build_stack_depth(self):
+        return lib().ref_scene_build_stack_depth(self._h)
+
+    def trace(self, o, d, tmin=0.001, tmax=3.4028234663852886e38, mode=TRAVERSE_BVH):
+        t = C.c_float()
+        prim = lib().ref_scene_trace(self._h, _f3(o), _f3(d), tmin, tmax, mode, C.byref(t))
+        return prim, (t.value if prim >= 0 else None)
+
+    def render(self, cam, width, height, spp, max_depth=10, seed=1984, sample_offset=0, ids_sample=0, mode=TRAVERSE_BVH, nthreads=None,
+               window=None, want_ids=True, want_accum=False):
+        """-> (fb [H,W,3] float32, ids [H,W] int32 or None, accum or None, RefStats).  window = (x0, y0, x1, y1)."""
+        if nthreads is None:
+            nthreads = min(os.cpu_count() or 1, 16)
+        x0, y0, x1, y1 = window if window is not None else (0, 0, width, height)
+        fb = np.zeros((height, width, 3), dtype=np.float32)
+        ids = np.full((height, width), -2, dtype=np.int32) if want_ids else None
+        accum = np.zeros((height, width, 3), dtype=np.float32) if want_accum else None
+        st = RefStats()
+        rc = lib().ref_render(self._h, cam.buf, width, height, spp, max_depth, seed, sample_offset, ids_sample, mode, nthreads, x0, y0, x1, y1,
+                              fb.ctypes.data, accum.ctypes.data if accum is not None else None, ids.ctypes.data if ids is not None else None,
+                              C.byref(st))
+        if rc != 0:
+            raise RuntimeError("oracle: ref_render failed (%d)" % rc)
+        return fb, ids, accum, st

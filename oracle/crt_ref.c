@@ -1,0 +1,891 @@
+/*
+ * oracle/crt_ref.c -- TEST INFRASTRUCTURE ONLY.  Never linked, imported or executed by the
+ * product (cudaraytracer_amd/, include/): only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load liboracle_crt.so.
+ *
+ * CPU restatement (plain C, float32) of the per-pixel path-tracing hot path of
+ * blueWhale903/CudaRayTracer.  Every function cites the reference file:line it follows
+ * (paths are relative to /root/reference/CudaRayTracer/).
+ *
+ * PARITY UNPINNED: the reference has no tests, golden vectors or fixtures,
+ * and cannot be compiled here (CUDA 12.6 + curand + glm + assimp + MSVC-isms; no nvcc, no glm,
+ * no assimp in this image), so nothing of the reference's own pins this restatement.  What pins
+ * it instead: (1) Philox4x32-10 known-answer vectors (Random123), (2) a brute-force fold over
+ * all primitives in reference leaf order (hittable_list.h:22-30 semantics) that must agree with
+ * the BVH traversal, (3) hand-computed per-function cases in tests/.
+ *
+ * Deliberate, documented deviations from the reference text:
+ *  - RNG: curand XORWOW (renderer.h:26,45; utility.h:72) is replaced by counter-based
+ *    Philox4x32-10 keyed on (pixel, sample, stage, block) -- BASELINE.json north_star.
+ *  - sinf/cosf (utility.h:93-95) are a fixed polynomial (ref_sincos) instead of libm so that the
+ *    same sequence of IEEE operations can be executed on gfx950; max error vs libm is checked
+ *    in tests/ (<= 2 ulp on (0, 2*pi]).
+ *  - Floating-point contraction: the reference source leaves contraction to nvcc (default
+ *    --fmad=true).  This file pins ONE contraction pattern, written out with fmaf(), and is
+ *    compiled with -ffp-contract=off so the compiler adds none: every source-level a*b+c
+ *    (glm::dot, glm::cross, ray.at, axpy-style updates) is a single fused multiply-add, evaluated
+ *    left to right.  Division and sqrt are IEEE correctly rounded.
+ *  - glm semantics (glm is not vendored by the reference; recalled from upstream):
+ *    min(a,b)=(b<a)?b:a, max(a,b)=(a<b)?b:a, normalize(v)=v*inversesqrt(dot(v,v)),
+ *    inversesqrt(x)=1/sqrt(x), length(v)=sqrt(dot(v,v)), vec/scalar = per-component division.
+ *  - Lambertian(Texture*) self-initialises its member in the reference (material.h:23, unusable);
+ *    here it holds the texture it is given (needed by BASELINE config 2).
+ *  - build_bvh's Range stack[32] (bvh.h:104) overflows for deep trees; here it is 128 deep.
+ *  - max path depth is a parameter (reference literal 10, camera.h:66).
+ */
+#define _GNU_SOURCE
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* L0 primitives: vec3 (glm::vec3), Ray (ray.h:9-25), Interval (interval.h:5-31)               */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { float x, y, z; } v3;
+
+static inline v3 V(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+static inline v3 vdivs(v3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }
+static inline v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
+/* a + s*b as one fma per component (pinned contraction of "a + s * b") */
+static inline v3 vfma(float s, v3 b, v3 a) { return V(fmaf(s, b.x, a.x), fmaf(s, b.y, a.y), fmaf(s, b.z, a.z)); }
+/* glm::dot: (a.x*b.x + a.y*b.y) + a.z*b.z, contracted left to right */
+static inline float vdot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+/* glm::cross: (x.y*y.z - y.y*x.z, x.z*y.x - y.z*x.x, x.x*y.y - y.x*x.y), each "p - q" one fma */
+static inline v3 vcross(v3 a, v3 b)
+{
+    return V(fmaf(a.y, b.z, -(b.y * a.z)), fmaf(a.z, b.x, -(b.z * a.x)), fmaf(a.x, b.y, -(b.x * a.y)));
+}
+static inline float vlength(v3 a) { return sqrtf(vdot(a, a)); }
+static inline v3 vnormalize(v3 a) { return vscale(a, 1.0f / sqrtf(vdot(a, a))); }
+static inline float glm_min(float a, float b) { return (b < a) ? b : a; }
+static inline float glm_max(float a, float b) { return (a < b) ? b : a; }
+
+typedef struct { v3 o, d; } ray_t;
+typedef struct { float min, max; } interval_t;
+typedef struct { interval_t x, y, z; } aabb_t;
+
+/* interval.h:11-14 */
+static inline interval_t interval_union(interval_t a, interval_t b)
+{
+    interval_t r;
+    r.min = a.min <= b.min ? a.min : b.min;
+    r.max = a.max >= b.max ? a.max : b.max;
+    return r;
+}
+/* aabb.h:12-16 */
+static inline aabb_t aabb_from_points(v3 a, v3 b)
+{
+    aabb_t r;
+    if (a.x < b.x) { r.x.min = a.x; r.x.max = b.x; } else { r.x.min = b.x; r.x.max = a.x; }
+    if (a.y < b.y) { r.y.min = a.y; r.y.max = b.y; } else { r.y.min = b.y; r.y.max = a.y; }
+    if (a.z < b.z) { r.z.min = a.z; r.z.max = b.z; } else { r.z.min = b.z; r.z.max = a.z; }
+    return r;
+}
+/* aabb.h:17-21 */
+static inline aabb_t aabb_union(aabb_t a, aabb_t b)
+{
+    aabb_t r;
+    r.x = interval_union(a.x, b.x);
+    r.y = interval_union(a.y, b.y);
+    r.z = interval_union(a.z, b.z);
+    return r;
+}
+static inline v3 aabb_min(aabb_t b) { return V(b.x.min, b.y.min, b.z.min); }
+static inline v3 aabb_max(aabb_t b) { return V(b.x.max, b.y.max, b.z.max); }
+
+/* aabb.h:72-92 fastAABBIntersect: the ray interval passed in is ignored (overwritten). */
+int ref_slab_test(const float bmin[3], const float bmax[3], const float o[3], const float d[3])
+{
+    const float eps = 1e-7f;
+    float ix = 1.0f / d[0], iy = 1.0f / d[1], iz = 1.0f / d[2];
+    float t0x = (bmin[0] - o[0]) * ix, t0y = (bmin[1] - o[1]) * iy, t0z = (bmin[2] - o[2]) * iz;
+    float t1x = (bmax[0] - o[0]) * ix, t1y = (bmax[1] - o[1]) * iy, t1z = (bmax[2] - o[2]) * iz;
+    float nx = glm_min(t0x, t1x) - eps, ny = glm_min(t0y, t1y) - eps, nz = glm_min(t0z, t1z) - eps;
+    float fx = glm_max(t0x, t1x) + eps, fy = glm_max(t0y, t1y) + eps, fz = glm_max(t0z, t1z) + eps;
+    float tmin = glm_max(glm_max(nx, ny), nz);
+    float tmax = glm_min(glm_min(fx, fy), fz);
+    return tmin <= tmax && tmax > 0.0f;
+}
+static inline int aabb_fast_intersect(const aabb_t *b, const ray_t *r)
+{
+    float mn[3] = { b->x.min, b->y.min, b->z.min }, mx[3] = { b->x.max, b->y.max, b->z.max };
+    float o[3] = { r->o.x, r->o.y, r->o.z }, d[3] = { r->d.x, r->d.y, r->d.z };
+    return ref_slab_test(mn, mx, o, d);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* RNG: Philox4x32-10 (Random123 / rocrand_philox4x32_10.h:286-303 round function)             */
+/* counter = (pixel_index, sample, stage, block); key = (seed_lo, seed_hi)                     */
+/* stage 0 = camera ray (camera.h:88-98), stage 1+depth = scatter at bounce `depth`            */
+/* ------------------------------------------------------------------------------------------ */
+void ref_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+/* curand_uniform's range (0,1] (utility.h:71-73, F14) on a 24-bit grid: exact in float32. */
+float ref_u01(uint32_t x) { return (float)((x >> 8) + 1u) * 5.9604644775390625e-08f; }
+
+typedef struct { uint32_t ctr[4], key[2], buf[4]; int have; } rng_t;
+static void rng_seek(rng_t *g, uint32_t pixel, uint32_t sample, uint32_t stage, uint64_t seed)
+{
+    g->ctr[0] = pixel; g->ctr[1] = sample; g->ctr[2] = stage; g->ctr[3] = 0;
+    g->key[0] = (uint32_t)seed; g->key[1] = (uint32_t)(seed >> 32);
+    g->have = 0;
+}
+static float rng_uniform(rng_t *g)
+{
+    if (g->have == 0) { ref_philox4x32_10(g->ctr, g->key, g->buf); g->ctr[3]++; g->have = 4; }
+    float u = ref_u01(g->buf[4 - g->have]);
+    g->have--;
+    return u;
+}
+/* utility.h:71-73 random_float: u*(max-min)+min, one fma */
+static inline float random_float(rng_t *g, float mn, float mx) { return fmaf(rng_uniform(g), mx - mn, mn); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* sin/cos on (0, 2*pi] -- stands in for sinf/cosf at utility.h:93-95 (see header)             */
+/* quadrant reduction x = k*(pi/2) + r, |r| <= pi/4 (3-term Cody-Waite), minimax polynomials   */
+/* ------------------------------------------------------------------------------------------ */
+void ref_sincos(float x, float *s, float *c)
+{
+    float kf = rintf(x * 0.636619772367581343f);           /* 2/pi */
+    int k = (int)kf;
+    float r = fmaf(kf, -1.5707962512969971f, x);           /* pi/2 split in three float parts */
+    r = fmaf(kf, -7.5497894158615964e-08f, r);
+    r = fmaf(kf, -5.3903029534742384e-15f, r);
+    float r2 = r * r;
+    /* sin(r) = r + r^3*(S1 + r2*(S2 + r2*(S3 + r2*S4))) */
+    float ps = fmaf(r2, 2.6083159809786593541503e-06f, -1.981069071916863322258e-04f);
+    ps = fmaf(ps, r2, 8.333307858556509017944336e-03f);
+    ps = fmaf(ps, r2, -1.666666567325592041015625e-01f);
+    float sr = fmaf(r * r2, ps, r);
+    /* cos(r) = 1 + r2*(C1 + r2*(C2 + r2*(C3 + r2*C4))) */
+    float pc = fmaf(r2, 2.443315711809948e-05f, -1.388731625493765e-03f);
+    pc = fmaf(pc, r2, 4.166664568298827e-02f);
+    pc = fmaf(pc, r2, -0.5f);
+    float cr = fmaf(r2, pc, 1.0f);
+    switch (k & 3) {
+    case 0: *s = sr; *c = cr; break;
+    case 1: *s = cr; *c = -sr; break;
+    case 2: *s = -sr; *c = -cr; break;
+    default: *s = -cr; *c = sr; break;
+    }
+}
+
+/* utility.h:90-98 random_unit_vector (F13: NOT uniform on the sphere; reproduced as written).
+ * draw order: theta first, then phi. */
+#define REF_PI_F 3.14159274101257324f        /* (float)M_PI */
+#define REF_2PI_F 6.28318548202514648f       /* (float)(2.0*M_PI) */
+static v3 random_unit_vector(rng_t *g)
+{
+    float theta = random_float(g, 0.0f, REF_PI_F);
+    float phi = random_float(g, 0.0f, REF_2PI_F);
+    float st, ct, sp, cp;
+    ref_sincos(theta, &st, &ct);
+    ref_sincos(phi, &sp, &cp);
+    return V(st * cp, st * sp, ct);
+}
+/* utility.h:100-109 random_in_unit_disk: <=10 rejection rounds then an unconditional 11th draw.
+ * draw order inside vec3(random, random, 0): x first, then y. */
+static v3 random_in_unit_disk(rng_t *g)
+{
+    for (int i = 0; i < 10; i++) {
+        float px = random_float(g, -1.0f, 1.0f);
+        float py = random_float(g, -1.0f, 1.0f);
+        v3 p = V(px, py, 0.0f);
+        if (vlength(p) < 1.0f) return p;
+    }
+    float px = random_float(g, -1.0f, 1.0f);
+    float py = random_float(g, -1.0f, 1.0f);
+    return V(px, py, 0.0f);
+}
+/* utility.h:111-113 reflect: v - 2*dot(v,n)*n */
+static inline v3 reflect(v3 v, v3 n) { float k = 2.0f * vdot(v, n); return vfma(-k, n, v); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Textures (texture.h) and materials (material.h) as tagged records                           */
+/* ------------------------------------------------------------------------------------------ */
+enum { REF_TEX_SOLID = 0, REF_TEX_CHECKER = 1 };
+enum { REF_MAT_LAMBERTIAN = 0, REF_MAT_METAL = 1, REF_MAT_DIFFUSE_LIGHT = 2, REF_MAT_DIELECTRIC = 3 };
+typedef struct { int type; v3 a, b; float inv_scale; } texture_t;
+typedef struct { int type; v3 albedo; float param; int tex; } material_t;
+
+/* texture.h:16 SolidColor::value, texture.h:31-39 CheckerTexture::value.
+ * `a` is the "even" argument, returned when the cell sum is ODD (texture.h:36-38, F15). */
+static v3 texture_value(const texture_t *t, v3 p)
+{
+    if (t->type == REF_TEX_SOLID) return t->a;
+    int xi = (int)floorf(t->inv_scale * p.x);
+    int yi = (int)floorf(t->inv_scale * p.y);
+    int zi = (int)floorf(t->inv_scale * p.z);
+    int is_even = ((xi + yi + zi) % 2) != 0;
+    return is_even ? t->a : t->b;
+}
+
+typedef struct {
+    v3 point, normal;
+    int material;
+    float t;
+    int front_face;
+    int prim;
+} hit_t;
+
+/* hittable.h:18-21 */
+static inline void set_face_normal(hit_t *h, const ray_t *r, v3 outward)
+{
+    h->front_face = vdot(r->d, outward) < 0.0f;
+    h->normal = h->front_face ? outward : vneg(outward);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Primitives: Triangle (triangle.h), Sphere (sphere.h)                                        */
+/* ------------------------------------------------------------------------------------------ */
+enum { PRIM_TRI = 0, PRIM_SPHERE = 1 };
+typedef struct {
+    int type, material;
+    v3 a, b, c;          /* triangle vertices; sphere: a = center, b.x = radius */
+    aabb_t bbox;
+    v3 minbbox, maxbbox; /* hittable.h:26-27, consumed by bvh.h:121-122 */
+} prim_t;
+
+/* triangle.h:28-46 Triangle::init -- bbox = min/max of vertices -/+ 1e-4 (utility.h:45-59 fminf/fmaxf folds) */
+static void triangle_init(prim_t *p)
+{
+    const float EPSILON = 1e-4f;
+    float mnx = fminf(fminf(fminf(p->a.x, p->a.x), p->b.x), p->c.x), mny = fminf(fminf(fminf(p->a.y, p->a.y), p->b.y), p->c.y);
+    float mnz = fminf(fminf(fminf(p->a.z, p->a.z), p->b.z), p->c.z);
+    float mxx = fmaxf(fmaxf(fmaxf(p->a.x, p->a.x), p->b.x), p->c.x), mxy = fmaxf(fmaxf(fmaxf(p->a.y, p->a.y), p->b.y), p->c.y);
+    float mxz = fmaxf(fmaxf(fmaxf(p->a.z, p->a.z), p->b.z), p->c.z);
+    p->bbox = aabb_from_points(V(mnx - EPSILON, mny - EPSILON, mnz - EPSILON), V(mxx + EPSILON, mxy + EPSILON, mxz + EPSILON));
+    p->minbbox = aabb_min(p->bbox);
+    p->maxbbox = aabb_max(p->bbox);
+}
+/* sphere.h:10-16 */
+static void sphere_init(prim_t *p, v3 center, float radius)
+{
+    p->a = center;
+    p->b = V(0.0f > radius ? 0.0f : radius, 0, 0); /* std::max(0.0f, radius) */
+    v3 rvec = V(radius, radius, radius);
+    p->bbox = aabb_from_points(vsub(center, rvec), vadd(center, rvec));
+    p->minbbox = aabb_min(p->bbox);
+    p->maxbbox = aabb_max(p->bbox);
+}
+
+/* triangle.h:48-86 Triangle::hit (Moller-Trumbore; u/v of the record are not written, F15) */
+static int triangle_hit(const prim_t *p, const ray_t *r, interval_t ray_t_, hit_t *rec)
+{
+    v3 edge_ab = vsub(p->b, p->a);
+    v3 edge_ac = vsub(p->c, p->a);
+    v3 pvec = vcross(r->d, edge_ac);
+    float det = vdot(edge_ab, pvec);
+    const float epsilon = 1e-7f;
+    if (fabsf(det) < epsilon) return 0;
+    float inv_det = 1.0f / det;
+    v3 tvec = vsub(r->o, p->a);
+    float u = vdot(tvec, pvec) * inv_det;
+    if (u < -epsilon || u > 1.0f + epsilon) return 0;
+    v3 qvec = vcross(tvec, edge_ab);
+    float v = vdot(r->d, qvec) * inv_det;
+    if (v < -epsilon || u + v > 1.0f + epsilon) return 0;
+    float t = vdot(edge_ac, qvec) * inv_det;
+    if (t < ray_t_.min - epsilon || t > ray_t_.max + epsilon) return 0;
+    rec->t = t;
+    rec->point = vfma(t, r->d, r->o);
+    v3 normal = vnormalize(vcross(edge_ab, edge_ac));
+    set_face_normal(rec, r, normal);
+    rec->material = p->material;
+    return 1;
+}
+/* C entry for unit tests: returns 1 and t,u... on hit */
+int ref_triangle_hit(const float a[3], const float b[3], const float c[3], const float o[3], const float d[3],
+                     float tmin, float tmax, float *t_out, float normal_out[3], int *front_out)
+{
+    prim_t p; memset(&p, 0, sizeof p);
+    p.a = V(a[0], a[1], a[2]); p.b = V(b[0], b[1], b[2]); p.c = V(c[0], c[1], c[2]);
+    ray_t r = { V(o[0], o[1], o[2]), V(d[0], d[1], d[2]) };
+    interval_t it = { tmin, tmax };
+    hit_t h; memset(&h, 0, sizeof h);
+    if (!triangle_hit(&p, &r, it, &h)) return 0;
+    *t_out = h.t; normal_out[0] = h.normal.x; normal_out[1] = h.normal.y; normal_out[2] = h.normal.z; *front_out = h.front_face;
+    return 1;
+}
+
+/* sphere.h:22-50 Sphere::hit; interval.h:19-21 contains() is closed on both ends */
+static int sphere_hit(const prim_t *p, const ray_t *r, interval_t ray_t_, hit_t *rec)
+{
+    v3 center = p->a;
+    float radius = p->b.x;
+    v3 oc = vsub(center, r->o);
+    float a = vdot(r->d, r->d);
+    float b = vdot(r->d, oc);
+    float c = fmaf(-radius, radius, vdot(oc, oc));
+    float discriminant = fmaf(b, b, -(a * c));
+    if (discriminant < 0) return 0;
+    float sqrt_discriminant = sqrtf(discriminant);
+    float root = (b - sqrt_discriminant) / a;
+    if (!(root >= ray_t_.min && root <= ray_t_.max)) {
+        root = (b + sqrt_discriminant) / a;
+        if (!(root >= ray_t_.min && root <= ray_t_.max)) return 0;
+    }
+    rec->t = root;
+    rec->point = vfma(root, r->d, r->o);
+    v3 outward = vdivs(vsub(rec->point, center), radius);
+    set_face_normal(rec, r, outward);
+    rec->material = p->material;
+    return 1;
+}
+int ref_sphere_hit(const float center[3], float radius, const float o[3], const float d[3],
+                   float tmin, float tmax, float *t_out, float normal_out[3], int *front_out)
+{
+    prim_t p; memset(&p, 0, sizeof p);
+    sphere_init(&p, V(center[0], center[1], center[2]), radius);
+    ray_t r = { V(o[0], o[1], o[2]), V(d[0], d[1], d[2]) };
+    interval_t it = { tmin, tmax };
+    hit_t h; memset(&h, 0, sizeof h);
+    if (!sphere_hit(&p, &r, it, &h)) return 0;
+    *t_out = h.t; normal_out[0] = h.normal.x; normal_out[1] = h.normal.y; normal_out[2] = h.normal.z; *front_out = h.front_face;
+    return 1;
+}
+static inline int prim_hit(const prim_t *p, const ray_t *r, interval_t it, hit_t *rec)
+{
+    return p->type == PRIM_TRI ? triangle_hit(p, r, it, rec) : sphere_hit(p, r, it, rec);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Scene, LBVH build (bvh.h, scene.h:158-177,288-307), node.h                                   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { aabb_t bbox; int child[2]; int id; } node_t; /* node.h:5-10, children as indices (-1 = nullptr) */
+
+typedef struct ref_scene {
+    prim_t *tris; uint32_t ntris, captris;
+    prim_t *spheres; uint32_t nspheres, capspheres;
+    texture_t *tex; uint32_t ntex;
+    material_t *mat; uint32_t nmat;
+    /* committed */
+    prim_t *list; uint32_t size;       /* hittable_list.h:9,11: all triangles then all spheres */
+    aabb_t scene_bbox;
+    uint32_t *morton, *indices;        /* sorted */
+    uint32_t *rank;                    /* rank[prim] = position in sorted order (= DFS leaf order) */
+    node_t *nodes;                     /* hittable_list.h:10; root = nodes[size] */
+    int max_depth_seen;
+} ref_scene;
+
+ref_scene *ref_scene_create(void) { return (ref_scene *)calloc(1, sizeof(ref_scene)); }
+void ref_scene_destroy(ref_scene *s)
+{
+    if (!s) return;
+    free(s->tris); free(s->spheres); free(s->tex); free(s->mat); free(s->list);
+    free(s->morton); free(s->indices); free(s->rank); free(s->nodes); free(s);
+}
+int ref_scene_add_texture(ref_scene *s, int type, const float a[3], const float b[3], float scale)
+{
+    s->tex = (texture_t *)realloc(s->tex, (s->ntex + 1) * sizeof(texture_t));
+    texture_t *t = &s->tex[s->ntex];
+    t->type = type; t->a = V(a[0], a[1], a[2]); t->b = b ? V(b[0], b[1], b[2]) : V(0, 0, 0);
+    t->inv_scale = (type == REF_TEX_CHECKER) ? 1.f / scale : 0.0f; /* texture.h:26 */
+    return (int)s->ntex++;
+}
+/* tex < 0: Lambertian(color)/DiffuseLight(color) build their own SolidColor (material.h:22,107) */
+int ref_scene_add_material(ref_scene *s, int type, const float rgb[3], float param, int tex)
+{
+    if (tex < 0 && (type == REF_MAT_LAMBERTIAN || type == REF_MAT_DIFFUSE_LIGHT)) tex = ref_scene_add_texture(s, REF_TEX_SOLID, rgb, NULL, 1.0f);
+    s->mat = (material_t *)realloc(s->mat, (s->nmat + 1) * sizeof(material_t));
+    material_t *m = &s->mat[s->nmat];
+    m->type = type; m->albedo = V(rgb[0], rgb[1], rgb[2]); m->param = param; m->tex = tex;
+    return (int)s->nmat++;
+}
+/* scene.h:92-155 load_triangles: vertex fetch by index, Triangle::init per triangle */
+int ref_scene_add_mesh(ref_scene *s, const float *xyz, uint32_t nverts, const uint32_t *idx, uint32_t ntris, int material)
+{
+    if (s->ntris + ntris > s->captris) {
+        s->captris = (s->ntris + ntris) * 2;
+        s->tris = (prim_t *)realloc(s->tris, (size_t)s->captris * sizeof(prim_t));
+    }
+    for (uint32_t t = 0; t < ntris; t++) {
+        uint32_t i0 = idx[3 * t], i1 = idx[3 * t + 1], i2 = idx[3 * t + 2];
+        if (i0 >= nverts || i1 >= nverts || i2 >= nverts) return -1;
+        prim_t *p = &s->tris[s->ntris + t];
+        memset(p, 0, sizeof *p);
+        p->type = PRIM_TRI; p->material = material;
+        p->a = V(xyz[3 * i0], xyz[3 * i0 + 1], xyz[3 * i0 + 2]);
+        p->b = V(xyz[3 * i1], xyz[3 * i1 + 1], xyz[3 * i1 + 2]);
+        p->c = V(xyz[3 * i2], xyz[3 * i2 + 1], xyz[3 * i2 + 2]);
+        triangle_init(p);
+    }
+    s->ntris += ntris;
+    return 0;
+}
+int ref_scene_add_sphere(ref_scene *s, const float c[3], float radius, int material)
+{
+    if (s->nspheres + 1 > s->capspheres) {
+        s->capspheres = (s->nspheres + 1) * 2;
+        s->spheres = (prim_t *)realloc(s->spheres, (size_t)s->capspheres * sizeof(prim_t));
+    }
+    prim_t *p = &s->spheres[s->nspheres++];
+    memset(p, 0, sizeof *p);
+    p->type = PRIM_SPHERE; p->material = material;
+    sphere_init(p, V(c[0], c[1], c[2]), radius);
+    return 0;
+}
+
+/* bvh.h:13-20 */
+static inline uint32_t expand_bits(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+/* bvh.h:24-33 */
+uint32_t ref_morton_3d(float px, float py, float pz)
+{
+    float x = fminf(fmaxf(px * 1024.0f, 0.0f), 1023.0f);
+    float y = fminf(fmaxf(py * 1024.0f, 0.0f), 1023.0f);
+    float z = fminf(fmaxf(pz * 1024.0f, 0.0f), 1023.0f);
+    uint32_t xx = expand_bits((uint32_t)x), yy = expand_bits((uint32_t)y), zz = expand_bits((uint32_t)z);
+    return xx * 4 + yy * 2 + zz;
+}
+static inline int clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
+/* bvh.h:50-89 */
+static uint32_t find_split(const uint32_t *codes, int first, int last)
+{
+    uint32_t firstCode = codes[first], lastCode = codes[last];
+    if (firstCode == lastCode) return (uint32_t)((first + last) >> 1);
+    int commonPrefix = clz32(firstCode ^ lastCode);
+    int split = first, step = last - first;
+    do {
+        step = (step + 1) >> 1;
+        int newSplit = split + step;
+        if (newSplit < last) {
+            uint32_t splitCode = codes[newSplit];
+            int splitPrefix = clz32(firstCode ^ splitCode);
+            if (splitPrefix > commonPrefix) split = newSplit;
+        }
+    } while (step > 1);
+    return (uint32_t)split;
+}
+
+typedef struct { uint32_t code, idx; } kv_t;
+static void stable_sort_kv(kv_t *a, kv_t *tmp, size_t n)
+{ /* bottom-up merge sort: stable, like thrust's radix sort_by_key on uint32 keys (scene.h:301) */
+    for (size_t w = 1; w < n; w *= 2) {
+        for (size_t lo = 0; lo < n; lo += 2 * w) {
+            size_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n;
+            size_t i = lo, j = mid, k = lo;
+            while (i < mid && j < hi) tmp[k++] = (a[j].code < a[i].code) ? a[j++] : a[i++];
+            while (i < mid) tmp[k++] = a[i++];
+            while (j < hi) tmp[k++] = a[j++];
+        }
+        memcpy(a, tmp, n * sizeof(kv_t));
+    }
+}
+
+int ref_scene_commit(ref_scene *s)
+{
+    uint32_t n = s->ntris + s->nspheres;
+    if (n < 2) return -1;
+    free(s->list); free(s->morton); free(s->indices); free(s->rank); free(s->nodes);
+    s->size = n;
+    s->list = (prim_t *)malloc((size_t)n * sizeof(prim_t));
+    memcpy(s->list, s->tris, (size_t)s->ntris * sizeof(prim_t));
+    memcpy(s->list + s->ntris, s->spheres, (size_t)s->nspheres * sizeof(prim_t));
+    /* scene.h:167-170 scene bbox = fold of unions in list order */
+    s->scene_bbox = s->list[0].bbox;
+    for (uint32_t i = 1; i < n; i++) s->scene_bbox = aabb_union(s->scene_bbox, s->list[i].bbox);
+    /* bvh.h:35-48 assign_morton_codes */
+    kv_t *kv = (kv_t *)malloc((size_t)n * sizeof(kv_t)), *tmp = (kv_t *)malloc((size_t)n * sizeof(kv_t));
+    v3 smin = aabb_min(s->scene_bbox), smax = aabb_max(s->scene_bbox);
+    v3 extent = vsub(smax, smin);
+    for (uint32_t i = 0; i < n; i++) {
+        aabb_t ob = s->list[i].bbox;
+        v3 centroid = vscale(vadd(aabb_min(ob), aabb_max(ob)), 0.5f); /* aabb.h:38-40 */
+        v3 d = vsub(centroid, smin);
+        v3 nc = V(d.x / extent.x, d.y / extent.y, d.z / extent.z);
+        kv[i].code = ref_morton_3d(nc.x, nc.y, nc.z);
+        kv[i].idx = i;
+    }
+    stable_sort_kv(kv, tmp, n);
+    free(tmp);
+    s->morton = (uint32_t *)malloc((size_t)n * 4); s->indices = (uint32_t *)malloc((size_t)n * 4); s->rank = (uint32_t *)malloc((size_t)n * 4);
+    for (uint32_t i = 0; i < n; i++) { s->morton[i] = kv[i].code; s->indices[i] = kv[i].idx; s->rank[kv[i].idx] = i; }
+    free(kv);
+    /* bvh.h:91-185 build_bvh (single thread, explicit range stack) */
+    uint32_t num_nodes = 2 * n - 1;
+    s->nodes = (node_t *)calloc(num_nodes, sizeof(node_t));
+    for (uint32_t i = 0; i < num_nodes; i++) { s->nodes[i].child[0] = s->nodes[i].child[1] = -1; s->nodes[i].id = -1; }
+    typedef struct { uint32_t first, last; int parent_index; int is_left_child; } range_t;
+    range_t stack[128];
+    int stack_size = 0, idx = 0;
+    s->max_depth_seen = 0;
+    stack[stack_size++] = (range_t){ 0, n - 1, -1, 1 };
+    while (stack_size > 0) {
+        range_t range = stack[--stack_size];
+        if (range.last == range.first) {
+            node_t *leaf = &s->nodes[range.first];
+            const prim_t *p = &s->list[s->indices[range.first]];
+            leaf->id = (int)s->indices[range.first];
+            leaf->child[0] = leaf->child[1] = -1;
+            leaf->bbox = aabb_from_points(p->minbbox, p->maxbbox);
+            if (range.parent_index != -1) s->nodes[range.parent_index].child[range.is_left_child ? 0 : 1] = (int)range.first;
+        } else {
+            uint32_t split = find_split(s->morton, (int)range.first, (int)range.last);
+            int internal = (int)n + idx;
+            idx++;
+            s->nodes[internal].id = -1;
+            if (range.parent_index != -1) s->nodes[range.parent_index].child[range.is_left_child ? 0 : 1] = internal;
+            if (stack_size + 2 > 128) return -2;
+            stack[stack_size++] = (range_t){ range.first, split, internal, 1 };
+            stack[stack_size++] = (range_t){ split + 1, range.last, internal, 0 };
+            if (stack_size > s->max_depth_seen) s->max_depth_seen = stack_size;
+        }
+    }
+    for (int i = (int)n - 1; i >= 0; i--) { /* bvh.h:161-181 bottom-up boxes */
+        if (n + (uint32_t)i >= num_nodes) continue;
+        node_t *in = &s->nodes[n + (uint32_t)i];
+        if (in->child[0] >= 0 && in->child[1] >= 0) in->bbox = aabb_union(s->nodes[in->child[0]].bbox, s->nodes[in->child[1]].bbox);
+        else if (in->child[0] >= 0) in->bbox = s->nodes[in->child[0]].bbox;
+        else if (in->child[1] >= 0) in->bbox = s->nodes[in->child[1]].bbox;
+    }
+    return 0;
+}
+uint32_t ref_scene_size(const ref_scene *s) { return s->size; }
+int ref_scene_build_stack_depth(const ref_scene *s) { return s->max_depth_seen; }
+void ref_scene_get_ranks(const ref_scene *s, uint32_t *out) { memcpy(out, s->rank, (size_t)s->size * 4); }
+void ref_scene_get_mortons(const ref_scene *s, uint32_t *codes_sorted, uint32_t *indices_sorted)
+{
+    memcpy(codes_sorted, s->morton, (size_t)s->size * 4); memcpy(indices_sorted, s->indices, (size_t)s->size * 4);
+}
+void ref_scene_get_bbox(const ref_scene *s, float out[6])
+{
+    out[0] = s->scene_bbox.x.min; out[1] = s->scene_bbox.y.min; out[2] = s->scene_bbox.z.min;
+    out[3] = s->scene_bbox.x.max; out[4] = s->scene_bbox.y.max; out[5] = s->scene_bbox.z.max;
+}
+void ref_scene_get_prim_bbox(const ref_scene *s, uint32_t i, float out[6])
+{
+    out[0] = s->list[i].minbbox.x; out[1] = s->list[i].minbbox.y; out[2] = s->list[i].minbbox.z;
+    out[3] = s->list[i].maxbbox.x; out[4] = s->list[i].maxbbox.y; out[5] = s->list[i].maxbbox.z;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* HittableList::hit (hittable_list.h:17-63)                                                   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { uint64_t rays, box_tests, tri_tests, sphere_tests; } ref_stats;
+
+enum { REF_TRAVERSE_BVH = 0, REF_TRAVERSE_BRUTE_LEAF_ORDER = 1, REF_TRAVERSE_BRUTE_LIST_ORDER = 2 };
+
+static int world_hit(const ref_scene *s, const ray_t *ray, interval_t ray_t_, hit_t *record, int mode, ref_stats *st)
+{
+    hit_t temp_rec;
+    int hit_anything = 0;
+    float closest_so_far = ray_t_.max;
+    st->rays++;
+    if (mode != REF_TRAVERSE_BVH) {
+        /* hittable_list.h:22-30 (#if BVH == 0), in list order or in the BVH's DFS leaf order */
+        for (uint32_t i = 0; i < s->size; i++) {
+            uint32_t id = mode == REF_TRAVERSE_BRUTE_LEAF_ORDER ? s->indices[i] : i;
+            interval_t it = { ray_t_.min, closest_so_far };
+            if (prim_hit(&s->list[id], ray, it, &temp_rec)) {
+                hit_anything = 1; closest_so_far = temp_rec.t; *record = temp_rec; record->prim = (int)id;
+            }
+        }
+        return hit_anything;
+    }
+    int stack[64];
+    uint32_t stack_size = 0;
+    stack[stack_size++] = (int)s->size; /* &d_nodes[size] */
+    while (stack_size > 0) {
+        const node_t *node = &s->nodes[stack[--stack_size]];
+        st->box_tests++;
+        if (!aabb_fast_intersect(&node->bbox, ray)) continue;
+        if (node->child[0] < 0 && node->child[1] < 0) {
+            int id = node->id;
+            interval_t it = { ray_t_.min, closest_so_far };
+            if (s->list[id].type == PRIM_TRI) st->tri_tests++; else st->sphere_tests++;
+            if (prim_hit(&s->list[id], ray, it, &temp_rec)) {
+                hit_anything = 1; closest_so_far = temp_rec.t; *record = temp_rec; record->prim = id;
+            }
+        }
+        if (node->child[1] >= 0) stack[stack_size++] = node->child[1];
+        if (node->child[0] >= 0) stack[stack_size++] = node->child[0];
+    }
+    return hit_anything;
+}
+
+/* single-ray entry for tests: returns prim id or -1 */
+int ref_scene_trace(const ref_scene *s, const float o[3], const float d[3], float tmin, float tmax, int mode, float *t_out)
+{
+    ray_t r = { V(o[0], o[1], o[2]), V(d[0], d[1], d[2]) };
+    interval_t it = { tmin, tmax };
+    hit_t h; memset(&h, 0, sizeof h);
+    ref_stats st = { 0, 0, 0, 0 };
+    if (!world_hit(s, &r, it, &h, mode, &st)) return -1;
+    if (t_out) *t_out = h.t;
+    return h.prim;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Materials: scatter / emitted (material.h)                                                   */
+/* ------------------------------------------------------------------------------------------ */
+/* material.h:10-12,109-111 */
+static v3 material_emitted(const ref_scene *s, const material_t *m, v3 p)
+{
+    if (m->type == REF_MAT_DIFFUSE_LIGHT) return texture_value(&s->tex[m->tex], p);
+    return V(0, 0, 0);
+}
+/* utility.h:115-120 */
+static v3 refract(v3 uv, v3 n, float etai_over_etat)
+{
+    float cos_theta = fminf(vdot(vneg(uv), n), 1.0f);
+    v3 r_out_perp = vscale(vfma(cos_theta, n, uv), etai_over_etat);
+    float l = vlength(r_out_perp);
+    v3 r_out_parallel = vscale(n, -sqrtf(fabsf(fmaf(-l, l, 1.0f)))); /* pow(x,2) == x*x exactly */
+    return vadd(r_out_perp, r_out_parallel);
+}
+/* material.h:96-101; pow(x,5) spelled as multiplications ((x*x)*(x*x))*x */
+static float reflectance(float cosine, float ri)
+{
+    float r0 = (1.0f - ri) / (1.0f + ri);
+    r0 = r0 * r0;
+    float x = 1.0f - cosine, x2 = x * x;
+    return fmaf(1.0f - r0, (x2 * x2) * x, r0);
+}
+static int material_scatter(const ref_scene *s, const material_t *m, const ray_t *ray, const hit_t *rec, v3 *attenuation, ray_t *scattered, rng_t *g)
+{
+    switch (m->type) {
+    case REF_MAT_LAMBERTIAN: { /* material.h:24-34 */
+        v3 dir = vadd(rec->normal, random_unit_vector(g));
+        if (vlength(dir) <= 1e-8f) dir = rec->normal;
+        scattered->o = rec->point; scattered->d = dir;
+        *attenuation = texture_value(&s->tex[m->tex], rec->point);
+        return 1;
+    }
+    case REF_MAT_METAL: { /* material.h:44-51: no absorb test, always true */
+        v3 reflected = reflect(ray->d, rec->normal);
+        reflected = vfma(m->param, random_unit_vector(g), vnormalize(reflected));
+        scattered->o = rec->point; scattered->d = reflected;
+        *attenuation = m->albedo;
+        return 1;
+    }
+    case REF_MAT_DIELECTRIC: { /* material.h:61-91 */
+        *attenuation = V(1.0f, 1.0f, 1.0f);
+        float ri = rec->front_face ? 1.0f / m->param : m->param;
+        v3 unit_direction = vnormalize(ray->d);
+        float cos_theta = fminf(vdot(vneg(unit_direction), rec->normal), 1.0f);
+        float sin_theta = sqrtf(fmaf(-cos_theta, cos_theta, 1.0f));
+        int is_reflect = ri * sin_theta > 1.0f;
+        v3 direction;
+        /* short-circuit ||: the uniform is drawn only when not total internal reflection */
+        if (is_reflect || reflectance(cos_theta, ri) > random_float(g, 0.0f, 1.0f)) direction = reflect(unit_direction, rec->normal);
+        else direction = refract(unit_direction, rec->normal, ri);
+        scattered->o = vfma(1e-3f, direction, rec->point); scattered->d = direction;
+        return 1;
+    }
+    default: /* material.h:14-16 base Material (DiffuseLight inherits it) */
+        return 0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Camera (camera.h)                                                                           */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint32_t image_width, image_height;
+    float defocus_angle, focus_distance;
+    v3 center, pixel00, pdh, pdv, u, v, w, disk_u, disk_v, background;
+} ref_camera;
+
+/* utility.h:67-69: degrees * M_PI / 180.0f is evaluated in double, returned as float */
+static inline float degrees_to_radians(float degrees) { return (float)((double)degrees * 3.14159265358979323846 / (double)180.0f); }
+
+/* camera.h:25-58.  F12: `aspect` is ignored, height = width / (16/9) from the member default. */
+void ref_camera_init(ref_camera *c, uint32_t width, const float from[3], const float at[3], const float vup_[3],
+                     float vfov, float aspect, float defocus_angle, float focus_dist)
+{
+    (void)aspect;
+    const float aspect_ratio = 16.0f / 9.0f;
+    c->image_width = width;
+    c->image_height = (uint32_t)((float)width / aspect_ratio);
+    c->image_height = c->image_height < 1 ? 1 : c->image_height;
+    v3 look_from = V(from[0], from[1], from[2]), look_at = V(at[0], at[1], at[2]), vup = V(vup_[0], vup_[1], vup_[2]);
+    c->center = look_from;
+    c->focus_distance = focus_dist;
+    /* the ctor parameter shadows the member (F12): get_ray tests the MEMBER default 0.6 (camera.h:20,94) */
+    c->defocus_angle = 0.6f;
+    float theta = degrees_to_radians(vfov);
+    float h = tanf(theta / 2.0f);
+    const float VIEWPORT_HEIGHT = 2.0f * h * focus_dist;
+    const float VIEWPORT_WIDTH = VIEWPORT_HEIGHT * ((float)c->image_width / (float)c->image_height);
+    c->w = vnormalize(vsub(look_from, look_at));
+    c->u = vnormalize(vcross(vup, c->w));
+    c->v = vcross(c->w, c->u);
+    v3 vh = vscale(c->u, VIEWPORT_WIDTH);
+    v3 vv = vscale(vneg(c->v), VIEWPORT_HEIGHT);
+    c->pdh = vdivs(vh, (float)c->image_width);
+    c->pdv = vdivs(vv, (float)c->image_height);
+    v3 ul = vsub(vsub(vsub(c->center, vscale(c->w, focus_dist)), vscale(vh, 0.5f)), vscale(vv, 0.5f));
+    c->pixel00 = vadd(ul, vscale(vadd(c->pdh, c->pdv), 0.5f));
+    float defocus_radius = focus_dist * tanf(degrees_to_radians(defocus_angle / 2.0f));
+    c->disk_u = vscale(c->u, defocus_radius);
+    c->disk_v = vscale(c->v, defocus_radius);
+    c->background = V(0, 0, 0);
+}
+
+/* camera.h:88-98 get_ray; sample_square draws x then y (camera.h:111-113) */
+static ray_t camera_get_ray(const ref_camera *c, float x, float y, rng_t *g)
+{
+    float ox = random_float(g, -0.5f, 0.5f);
+    float oy = random_float(g, -0.5f, 0.5f);
+    v3 pixel_center = vfma(oy + y, c->pdv, vfma(ox + x, c->pdh, c->pixel00));
+    v3 origin = c->center;
+    if (!(c->defocus_angle <= 0.0f)) { /* camera.h:115-119 */
+        v3 p = random_in_unit_disk(g);
+        origin = vfma(p.y, c->disk_v, vfma(p.x, c->disk_u, c->center));
+    }
+    ray_t r = { origin, vsub(pixel_center, origin) };
+    return r;
+}
+
+/* camera.h:60-87 ray_color */
+static v3 camera_ray_color(const ref_camera *c, ray_t ray, const ref_scene *world, uint32_t max_depth, int mode,
+                           uint32_t pixel, uint32_t sample, uint64_t seed, ref_stats *st, int *primary_id)
+{
+    ray_t cur_ray = ray;
+    v3 cur_attenuation = V(1.0f, 1.0f, 1.0f);
+    v3 final_color = V(0.0f, 0.0f, 0.0f);
+    for (uint32_t depth = 0; depth < max_depth; depth++) {
+        hit_t rec; memset(&rec, 0, sizeof rec);
+        interval_t it = { 0.001f, FLT_MAX };
+        int hit = world_hit(world, &cur_ray, it, &rec, mode, st);
+        if (depth == 0 && primary_id) *primary_id = hit ? rec.prim : -1;
+        if (!hit) {
+            final_color = V(fmaf(cur_attenuation.x, c->background.x, final_color.x), fmaf(cur_attenuation.y, c->background.y, final_color.y),
+                            fmaf(cur_attenuation.z, c->background.z, final_color.z));
+            break;
+        }
+        const material_t *m = &world->mat[rec.material];
+        v3 emission = material_emitted(world, m, rec.point);
+        final_color = V(fmaf(cur_attenuation.x, emission.x, final_color.x), fmaf(cur_attenuation.y, emission.y, final_color.y),
+                        fmaf(cur_attenuation.z, emission.z, final_color.z));
+        ray_t scattered;
+        v3 attenuation;
+        rng_t g;
+        rng_seek(&g, pixel, sample, 1u + depth, seed);
+        if (!material_scatter(world, m, &cur_ray, &rec, &attenuation, &scattered, &g)) break;
+        cur_attenuation = vmul(cur_attenuation, attenuation);
+        cur_ray = scattered;
+    }
+    return final_color;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* kernel_render (renderer.h:18-38) + write_color (color.h:5-24), threaded over rows           */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const ref_scene *scene; const ref_camera *cam;
+    uint32_t W, H, spp, max_depth, sample_offset, ids_sample;
+    uint32_t x0, y0, x1, y1;         /* pixel window [x0,x1) x [y0,y1) actually rendered */
+    uint64_t seed;
+    int mode;
+    float *fb, *accum; int32_t *ids;
+    volatile uint32_t next_row;
+    ref_stats stats; pthread_mutex_t lock;
+} job_t;
+
+static void *render_worker(void *arg)
+{
+    job_t *j = (job_t *)arg;
+    ref_stats st = { 0, 0, 0, 0 };
+    for (;;) {
+        uint32_t row = __sync_fetch_and_add(&j->next_row, 1);
+        if (row >= j->y1) break;
+        for (uint32_t i = j->x0; i < j->x1; i++) {
+            uint32_t pixel_index = row * j->W + i;
+            v3 col = V(0.0f, 0.0f, 0.0f);
+            for (uint32_t sidx = 0; sidx < j->spp; sidx++) {
+                uint32_t s = j->sample_offset + sidx;
+                rng_t g;
+                rng_seek(&g, pixel_index, s, 0u, j->seed);
+                ray_t r = camera_get_ray(j->cam, (float)i, (float)row, &g);
+                int pid = -1;
+                v3 c = camera_ray_color(j->cam, r, j->scene, j->max_depth, j->mode, pixel_index, s, j->seed, &st, &pid);
+                col = vadd(col, c);
+                if (j->ids && s == j->ids_sample) j->ids[pixel_index] = pid;
+            }
+            if (j->accum) { j->accum[3 * pixel_index] = col.x; j->accum[3 * pixel_index + 1] = col.y; j->accum[3 * pixel_index + 2] = col.z; }
+            if (j->fb) {
+                col = vdivs(col, (float)j->spp);
+                /* color.h:5-11: x > 0 ? sqrtf(x) : 0 */
+                j->fb[3 * pixel_index] = col.x > 0 ? sqrtf(col.x) : 0.0f;
+                j->fb[3 * pixel_index + 1] = col.y > 0 ? sqrtf(col.y) : 0.0f;
+                j->fb[3 * pixel_index + 2] = col.z > 0 ? sqrtf(col.z) : 0.0f;
+            }
+        }
+    }
+    pthread_mutex_lock(&j->lock);
+    j->stats.rays += st.rays; j->stats.box_tests += st.box_tests; j->stats.tri_tests += st.tri_tests; j->stats.sphere_tests += st.sphere_tests;
+    pthread_mutex_unlock(&j->lock);
+    return NULL;
+}
+
+/*
+ * Render samples [sample_offset, sample_offset+spp) of the window [x0,x1) x [y0,y1) of a W x H frame.
+ * fb    : W*H*3 gamma-encoded average (renderer.h:36-37), may be NULL
+ * accum : W*H*3 raw per-pixel sums before the division (for sample-split checks), may be NULL
+ * ids   : W*H primary-hit primitive ids of sample `ids_sample` (-1 = miss), may be NULL
+ * Pixels outside the window are left untouched.
+ */
+int ref_render(const ref_scene *scene, const ref_camera *cam, uint32_t W, uint32_t H, uint32_t spp, uint32_t max_depth,
+               uint64_t seed, uint32_t sample_offset, uint32_t ids_sample, int mode, int nthreads,
+               uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+               float *fb, float *accum, int32_t *ids, ref_stats *stats_out)
+{
+    if (!scene || !scene->nodes || !cam || spp == 0) return -1;
+    if (x1 > W) x1 = W;
+    if (y1 > H) y1 = H;
+    job_t j; memset(&j, 0, sizeof j);
+    j.scene = scene; j.cam = cam; j.W = W; j.H = H; j.spp = spp; j.max_depth = max_depth; j.sample_offset = sample_offset;
+    j.ids_sample = ids_sample; j.seed = seed; j.mode = mode; j.fb = fb; j.accum = accum; j.ids = ids;
+    j.x0 = x0; j.y0 = y0; j.x1 = x1; j.y1 = y1; j.next_row = y0;
+    pthread_mutex_init(&j.lock, NULL);
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    pthread_t th[256];
+    for (int t = 0; t < nthreads; t++) pthread_create(&th[t], NULL, render_worker, &j);
+    for (int t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
+    pthread_mutex_destroy(&j.lock);
+    if (stats_out) *stats_out = j.stats;
+    return 0;
+}
+
+/* camera-ray generation alone, for unit tests of the RNG stream shape (a4, a5) */
+void ref_camera_get_ray(const ref_camera *cam, uint32_t W, uint32_t i, uint32_t j, uint32_t sample, uint64_t seed, float o[3], float d[3])
+{
+    rng_t g;
+    rng_seek(&g, j * W + i, sample, 0u, seed);
+    ray_t r = camera_get_ray(cam, (float)i, (float)j, &g);
+    o[0] = r.o.x; o[1] = r.o.y; o[2] = r.o.z; d[0] = r.d.x; d[1] = r.d.y; d[2] = r.d.z;
+}
+void ref_random_unit_vector(uint32_t pixel, uint32_t sample, uint32_t stage, uint64_t seed, float out[3])
+{
+    rng_t g;
+    rng_seek(&g, pixel, sample, stage, seed);
+    v3 r = random_unit_vector(&g);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+uint32_t ref_sizeof_camera(void) { return (uint32_t)sizeof(ref_camera); }
