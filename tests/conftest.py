@@ -1,0 +1,47 @@
+import os
+import subprocess
+import sys
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _ensure(path, makedir):
+    """Build a CPU-side test artefact if it is missing (the HIP library itself is built by __graft_entry__.build())."""
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", makedir], stdout=subprocess.DEVNULL)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    _ensure(os.path.join(REPO, "oracle", "liboracle_crt.so"), os.path.join(REPO, "oracle"))
+    from oracle import binding
+    binding.lib()
+    return binding
+
+
+@pytest.fixture(scope="session")
+def hostsim():
+    _ensure(os.path.join(REPO, "tests", "hostsim", "libhostsim.so"), os.path.join(REPO, "tests", "hostsim"))
+    from tests import helpers
+    return helpers.HostSim()
+
+
+@pytest.fixture(scope="session")
+def capi():
+    from cudaraytracer_amd import capi as c
+    c.lib()  # raises loudly if libcrt_hip.so is not built
+    return c
+
+
+@pytest.fixture(scope="session")
+def scenes(capi):
+    from cudaraytracer_amd import scenes as s
+    return s

@@ -1,0 +1,129 @@
+// tests/hostsim/hostsim.cpp -- TEST-ONLY host build of the product's per-lane code (crt_core.h / crt_traverse.h) and
+// host scene preparation (crt_api.cpp / crt_bvh.cpp).  It lets the CPU test suite single-step the exact traversal /
+// tie-fold / shading logic the gfx950 kernel runs, one lane at a time, and compare it with the oracle before any GPU
+// is involved.  It is never loaded by the cudaraytracer_amd package and is not a rendering fallback: the kernel
+// launchers are stubbed to fail.
+#include "../../cudaraytracer_amd/csrc/crt_api.cpp"
+
+namespace crt {
+hipError_t launch_render(const SceneView &, const CameraPOD &, const RenderArgs &, float *, int *, unsigned long long *, bool, hipStream_t)
+{
+    return hipErrorNoDevice;
+}
+hipError_t launch_untile(const float *, uint32_t, uint32_t, uint32_t, float *, hipStream_t) { return hipErrorNoDevice; }
+hipError_t launch_finalize(const float *, size_t, uint32_t, float *, hipStream_t) { return hipErrorNoDevice; }
+} // namespace crt
+
+namespace {
+struct ArrayStack {
+    int v[CRT_STACK_DEPTH];
+    int sp = 0;
+    int max_sp = 0;
+    void reset() { sp = 0; }
+    void push(int x) { if (sp < CRT_STACK_DEPTH) v[sp] = x; sp++; if (sp > max_sp) max_sp = sp; }
+    int pop() { if (sp == 0) return CRT_BVH_NONE; sp--; return v[sp]; }
+};
+struct HostCounters {
+    uint64_t nodes = 0, tris = 0, spheres = 0, rays = 0, refolds = 0;
+    void node() { nodes++; }
+    void tri() { tris++; }
+    void sphere() { spheres++; }
+    void ray() { rays++; }
+    void refold() { refolds++; }
+};
+SceneView host_view(const crt_scene *s, std::vector<Sphere> &spheres)
+{
+    spheres.resize(s->spheres.size());
+    for (size_t k = 0; k < s->spheres.size(); k++) {
+        Sphere &o = spheres[k];
+        o.cx = s->spheres[k].center.x; o.cy = s->spheres[k].center.y; o.cz = s->spheres[k].center.z; o.radius = s->spheres[k].radius;
+        o.id = (int)(s->tris.size() + k); o.rank = (int)s->rank[s->tris.size() + k]; o.mat = s->spheres[k].material; o.pad = 0;
+    }
+    SceneView v{};
+    v.nodes = s->bvh.nodes.data(); v.tris = s->bvh.tris.data(); v.spheres = spheres.data(); v.mats = s->mats.data(); v.texs = s->texs.data();
+    v.root_ref = s->bvh.root_ref; v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size();
+    v.root_min = s->bvh.root_box.mn; v.root_max = s->bvh.root_box.mx;
+    return v;
+}
+} // namespace
+
+// Same contract as crt_render (row-major output, host pointers), executed lane by lane on the CPU.
+// stats_out[0..5] = rays, nodes, tri tests, sphere tests, tie refolds, deepest stack use.
+extern "C" int hostsim_render(const crt_scene *s, const crt_camera *cam, const crt_render_params *p, float *out_rgb, int32_t *out_ids,
+                              uint64_t *stats_out)
+{
+    if (!s || !s->prepared || !cam || !p || !out_rgb) return CRT_ERR_INVALID;
+    std::vector<Sphere> spheres;
+    const SceneView sc = host_view(s, spheres);
+    const CameraPOD &c = *reinterpret_cast<const CameraPOD *>(cam);
+    HostCounters cnt;
+    ArrayStack stack;
+    const uint32_t tiles_x = (p->width + 7u) / 8u, tiles_y = (p->height + 7u) / 8u;
+    for (uint32_t tile = p->tile_rank; tile < tiles_x * tiles_y; tile += p->tile_ranks) {
+        const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+        for (uint32_t lane = 0; lane < 64; lane++) {
+            const uint32_t i = tx * 8u + (lane & 7u), j = ty * 8u + (lane >> 3);
+            if (i >= p->width || j >= p->height) continue;
+            const uint32_t pixel = j * p->width + i;
+            f3 col = mk3(0.0f, 0.0f, 0.0f);
+            for (uint32_t k = 0; k < p->spp; k++) {
+                const uint32_t sample = p->sample_offset + k;
+                int prim;
+                const f3 r = sample_radiance(sc, c, i, j, pixel, sample, p->max_depth, (uint32_t)p->seed, (uint32_t)(p->seed >> 32), stack, cnt, prim);
+                col = col + r;
+                if (out_ids && sample == p->ids_sample) out_ids[pixel] = prim;
+            }
+            f3 o = col;
+            if (!(p->flags & CRT_OUT_ACCUM)) {
+                o = div3(col, (float)p->spp);
+                o.x = o.x > 0 ? sqrtf(o.x) : 0.0f; o.y = o.y > 0 ? sqrtf(o.y) : 0.0f; o.z = o.z > 0 ? sqrtf(o.z) : 0.0f;
+            }
+            out_rgb[3 * (size_t)pixel] = o.x; out_rgb[3 * (size_t)pixel + 1] = o.y; out_rgb[3 * (size_t)pixel + 2] = o.z;
+        }
+    }
+    if (stats_out) {
+        stats_out[0] = cnt.rays; stats_out[1] = cnt.nodes; stats_out[2] = cnt.tris; stats_out[3] = cnt.spheres; stats_out[4] = cnt.refolds;
+        stats_out[5] = (uint64_t)stack.max_sp;
+    }
+    return CRT_OK;
+}
+
+// one ray through the product traversal: returns primitive id (-1 miss), writes t; force_tie_path != 0 runs the
+// reference-order fold even when the fast path saw no near tie (the two must agree).
+extern "C" int hostsim_trace(const crt_scene *s, const float o_[3], const float d_[3], float tmin, float *t_out, int force_tie_path, int *took_tie_path)
+{
+    if (!s || !s->prepared) return -3;
+    std::vector<Sphere> spheres;
+    const SceneView sc = host_view(s, spheres);
+    HostCounters cnt;
+    ArrayStack stack;
+    const f3 o = mk3(o_[0], o_[1], o_[2]), d = mk3(d_[0], d_[1], d_[2]);
+    float t = 0.0f;
+    int code;
+    if (!force_tie_path) {
+        code = closest_hit(sc, o, d, tmin, FLT_MAX, t, stack, cnt);
+    } else {
+        Search q; q.t = FLT_MAX; q.code = -1; q.rank = 0; q.near_tie = false;
+        walk<MODE_CLOSEST>(sc, o, d, tmin, q, 0, 0.0f, stack, cnt);
+        code = -1;
+        if (q.code >= 0) {
+            cnt.refold();
+            const float t_hi = q.t + CRT_TIE_WINDOW;
+            float closest = FLT_MAX;
+            int after = -1;
+            for (;;) {
+                Search n; n.t = 0.0f; n.code = -1; n.rank = 0x7FFFFFFF; n.near_tie = false;
+                walk<MODE_NEXT_RANK>(sc, o, d, tmin, n, after, t_hi, stack, cnt);
+                if (n.code < 0) break;
+                const bool is_tri = (uint32_t)n.code < sc.ntris;
+                if (is_tri ? triangle_accepts(n.t, closest) : sphere_accepts(n.t, closest)) { closest = n.t; code = n.code; }
+                after = n.rank;
+            }
+            t = closest;
+        }
+    }
+    if (took_tie_path) *took_tie_path = cnt.refolds > 0;
+    if (code < 0) return -1;
+    if (t_out) *t_out = t;
+    return surface_at(sc, code, o, d, t).prim;
+}
