@@ -1,0 +1,185 @@
+"""bench.py -- headline benchmark: Mrays/s (all bounces) + ms/frame, cats.obj 1920x1080 64 spp (BASELINE.json).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--mode tile|sample] [--workload cats|cat_checker|cat_grid]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = one full frame of the workload.  N ranks split the SAME frame (strong scaling): tile mode deals 8x8 tiles
+round-robin and all-gathers them over RCCL; sample mode splits the samples and reduces float sums.  The scene, camera
+and output buffers are resident in HBM before the timed region; `value` = path segments traced by all ranks / wall time.
+Rank 0 prints ONE JSON line.  `roofline` is for the render kernel (VALU-issue bound: no dense contraction, scene
+L2-resident; HBM figures given beside it); `cpu_baseline` times the oracle (CPU restatement of the reference) on the
+host cores on a bounded sample of the same workload (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch  # before the HIP library: one HIP runtime per process (see tests/conftest.py)
+import torch.distributed as dist
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+from cudaraytracer_amd import capi, scenes  # noqa: E402
+from cudaraytracer_amd.dist import SampleFrame, TileFrame  # noqa: E402
+
+WORKLOADS = {
+    # name: (scene builder, width, height, spp, max_depth, camera overrides)
+    "cats": ("cats", 1920, 1080, 64, 10, {}),            # BASELINE configs[2] = the config the metric is quoted on
+    "cat_checker": ("cat_checker", 1920, 1080, 64, 8, {}),  # configs[1]
+    "cat_grid": ("cat_grid", 3840, 2160, 16, 10, scenes.GRID_CAMERA),  # configs[3]
+    "cats_4k": ("cats", 3840, 2160, 1024, 10, {}),       # configs[4] (use --mode sample)
+}
+
+# /opt/skills/guides/MI355X_MICROARCH.md: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (= the 157.3 TFLOP/s fp32 spec / 2)
+VALU_PEAK_TLANEOPS_256CU = 256 * 4 * 32 * 2.4e9 / 1e12
+HBM_PEAK_GBS = 8000.0
+
+
+def lane_ops(st):
+    # 30 per box test (2 per node), 60 per triangle test, 25 per sphere test, 120 per shaded bounce
+    return 30.0 * 2 * st.nodes + 60.0 * st.tri_tests + 25.0 * st.sphere_tests + 120.0 * st.shaded_hits
+
+
+def algorithmic_bytes(st, width, height):
+    return 64.0 * st.nodes + 48.0 * st.tri_tests + 32.0 * st.sphere_tests + 12.0 * width * height
+
+
+def cpu_baseline(desc, cam_params, width, height, max_depth, seed, target_seconds=12.0):
+    """Oracle (oracle/crt_ref.c, reference traversal semantics) on the host cores: whole frame, few samples."""
+    from oracle import binding as ob
+    rs = ob.RefScene(desc)
+    cam = ob.make_camera(cam_params, width)
+    cores = min(os.cpu_count() or 1, 16)
+    t0 = time.perf_counter()
+    _, _, _, st = rs.render(cam, width, height, 1, max_depth=max_depth, seed=seed, nthreads=cores, want_ids=False)
+    t1 = time.perf_counter() - t0
+    spp = int(max(1, min(64, target_seconds / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    _, _, _, st = rs.render(cam, width, height, spp, max_depth=max_depth, seed=seed, nthreads=cores, want_ids=False)
+    dt = time.perf_counter() - t0
+    return dict(value=st.rays / dt / 1e6, unit="Mrays/s", cores=cores, kind="port",
+                sample="whole %dx%d frame, samples 0..%d of the workload (%d rays, %.1f s, %d threads over rows)" % (width, height, spp - 1, st.rays, dt, cores))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mode", choices=["tile", "sample"], default="tile")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cats")
+    ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug; invalidates the headline number)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py: no HIP device visible; the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    builder, W, H, spp, depth, cam_over = WORKLOADS[args.workload]
+    if args.spp:
+        spp = args.spp
+    seed = scenes.REF_SEED
+    desc = getattr(scenes, builder)()
+    scene = scenes.build(desc, local_rank)
+    cam_params, cam = scenes.make_camera(W, **cam_over)
+    info = scene.info()
+
+    if args.mode == "tile":
+        frame = TileFrame(W, H, world, rank, device)
+
+        def launch(want_stats=False, flags=0):
+            return frame.render_local(scene, cam, spp, depth, seed, want_stats=want_stats, flags=flags)
+        finish = frame.gather
+    else:
+        frame = SampleFrame(W, H, spp, world, rank, device)
+
+        def launch(want_stats=False, flags=0):
+            return frame.render_local(scene, cam, depth, seed, want_stats=want_stats)
+        finish = frame.reduce
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        launch()
+        finish()
+    barrier()
+    kernel_ms = []
+    rays_local = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = launch(want_stats=True)   # stats: library hipEvents around the kernel on this stream (+ one stream sync per frame)
+        finish()
+        kernel_ms.append(st.kernel_ms)
+        rays_local = st.rays
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed, float(rays_local), sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=device)
+    if world > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, rays_frame, kernel_avg_ms = float(tmax[0]), float(tsum[1]), float(tmax[2])
+    else:
+        rays_frame, kernel_avg_ms = float(rays_local), float(t[2])
+
+    # work counts of this rank's launch (instrumented kernel, outside the timed region; counts are deterministic)
+    if args.mode == "tile":
+        stw = frame.render_local(scene, cam, spp, depth, seed, want_stats=True, flags=capi.COUNT_WORK)
+    else:
+        stw = scene.render(cam, W, H, frame.spp_local, max_depth=depth, seed=seed, sample_offset=rank * frame.spp_local,
+                           flags=capi.OUT_ACCUM | capi.COUNT_WORK, out_rgb=frame.accum.data_ptr(), want_stats=True)[2]
+    torch.cuda.synchronize()
+
+    if rank == 0:
+        props = torch.cuda.get_device_properties(device)
+        cus = props.multi_processor_count
+        valu_peak = VALU_PEAK_TLANEOPS_256CU * cus / 256.0
+        ksec = kernel_avg_ms / 1e3
+        ops = lane_ops(stw)
+        abytes = algorithmic_bytes(stw, W, H) if args.mode == "tile" else algorithmic_bytes(stw, W, H)
+        out = {
+            "metric": "Mrays/s (all bounces)", "value": rays_frame * args.steps / elapsed / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s %dx%d %dspp depth %d (models/%s + ground + emissive sphere, seed %d)" %
+                       (args.workload, W, H, spp, depth, "cat.obj" if builder != "cats" else "cats.obj", seed),
+                       "partition": "%s x%d" % (args.mode, world), "triangles": info.num_triangles, "bvh_nodes": info.num_nodes,
+                       "rays_per_frame": int(rays_frame), "device_cus": cus},
+            "roofline": {"bound": "valu", "achieved": ops / ksec / 1e12, "peak": valu_peak, "unit": "Tlane-op/s",
+                         "frac": ops / ksec / 1e12 / valu_peak, "traffic": None,
+                         "kernel": "render_kernel", "kernel_ms": kernel_avg_ms, "rays_per_launch": int(stw.rays),
+                         "nodes_per_ray": stw.nodes / max(stw.rays, 1), "tri_tests_per_ray": stw.tri_tests / max(stw.rays, 1),
+                         "hbm": {"bound": "hbm", "achieved": abytes / ksec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": abytes / ksec / 1e9 / HBM_PEAK_GBS, "note": "algorithmic node+triangle+sphere+framebuffer bytes; "
+                                 "the scene (%d KiB) is cache resident, so this is request rate, not HBM traffic" %
+                                 ((info.node_bytes + info.triangle_bytes + info.sphere_bytes) // 1024)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(desc, cam_params, W, H, depth, seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -40,7 +40,7 @@ class RenderParams(C.Structure):  # crt_render_params
 
 class Stats(C.Structure):  # crt_stats
     _fields_ = [("rays", C.c_uint64), ("nodes", C.c_uint64), ("tri_tests", C.c_uint64), ("sphere_tests", C.c_uint64), ("tie_refolds", C.c_uint64),
-                ("kernel_ms", C.c_float), ("reserved", C.c_uint32)]
+                ("shaded_hits", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_uint32)]
 
 
 class SceneInfo(C.Structure):  # crt_scene_info

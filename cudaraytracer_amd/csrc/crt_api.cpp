@@ -457,7 +457,7 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
         HIP_TRY(hipMemcpyAsync(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         memset(stats, 0, sizeof *stats);
-        stats->rays = c[0]; stats->nodes = c[1]; stats->tri_tests = c[2]; stats->sphere_tests = c[3]; stats->tie_refolds = c[4];
+        stats->rays = c[0]; stats->nodes = c[1]; stats->tri_tests = c[2]; stats->sphere_tests = c[3]; stats->tie_refolds = c[4]; stats->shaded_hits = c[5];
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
         stats->kernel_ms = ms;

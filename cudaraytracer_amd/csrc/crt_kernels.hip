@@ -25,12 +25,13 @@ struct LdsStack {
 };
 
 struct RegCounters {
-    uint32_t nodes = 0, tris = 0, spheres = 0, rays = 0, refolds = 0;
+    uint32_t nodes = 0, tris = 0, spheres = 0, rays = 0, refolds = 0, shades = 0;
     __device__ __forceinline__ void node() { nodes++; }
     __device__ __forceinline__ void tri() { tris++; }
     __device__ __forceinline__ void sphere() { spheres++; }
     __device__ __forceinline__ void ray() { rays++; }
     __device__ __forceinline__ void refold() { refolds++; }
+    __device__ __forceinline__ void shade() { shades++; }
 };
 struct RayCounters { // always-on: rays and tie refolds only
     uint32_t rays = 0, refolds = 0;
@@ -39,6 +40,7 @@ struct RayCounters { // always-on: rays and tie refolds only
     __device__ __forceinline__ void sphere() {}
     __device__ __forceinline__ void ray() { rays++; }
     __device__ __forceinline__ void refold() { refolds++; }
+    __device__ __forceinline__ void shade() {}
 };
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
@@ -96,8 +98,9 @@ __global__ __launch_bounds__(64) void render_kernel(SceneView sc, CameraPOD cam,
         if (refolds) atomicAdd(&counters[4], (unsigned long long)refolds);
     }
     if constexpr (COUNT_WORK) {
-        const uint32_t n = wave_sum(cnt.nodes), t = wave_sum(cnt.tris), sp = wave_sum(cnt.spheres);
+        const uint32_t n = wave_sum(cnt.nodes), t = wave_sum(cnt.tris), sp = wave_sum(cnt.spheres), sh = wave_sum(cnt.shades);
         if (lane == 0) {
+            atomicAdd(&counters[5], (unsigned long long)sh);
             atomicAdd(&counters[1], (unsigned long long)n);
             atomicAdd(&counters[2], (unsigned long long)t);
             atomicAdd(&counters[3], (unsigned long long)sp);

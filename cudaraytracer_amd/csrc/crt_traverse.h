@@ -62,6 +62,7 @@ struct NoCounters {
     CRT_HD void sphere() {}
     CRT_HD void ray() {}
     CRT_HD void refold() {}
+    CRT_HD void shade() {}
 };
 
 enum { MODE_CLOSEST = 0, MODE_NEXT_RANK = 1 };
@@ -251,6 +252,7 @@ CRT_HD f3 sample_radiance(const SceneView &sc, const CameraPOD &cam, uint32_t i,
             break;
         }
         const Surface sf = surface_at(sc, code, o, d, t);
+        cnt.shade();
         if (depth == 0) primary_prim = sf.prim;
         const Material m = sc.mats[sf.material];
         const f3 e = emitted(m, sc.texs, sf.point);

@@ -126,6 +126,7 @@ typedef struct crt_stats {
     uint64_t tri_tests;     /* 48-byte triangle records tested  (CRT_COUNT_WORK)                            */
     uint64_t sphere_tests;  /* 32-byte sphere records tested    (CRT_COUNT_WORK)                            */
     uint64_t tie_refolds;   /* rays that took the exact reference-order tie fold                            */
+    uint64_t shaded_hits;   /* rays that hit something and were shaded (CRT_COUNT_WORK)                     */
     float kernel_ms;        /* hipEvent time of the render kernel on `stream`                               */
     uint32_t reserved;
 } crt_stats;

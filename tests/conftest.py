@@ -4,6 +4,14 @@ import sys
 
 import pytest
 
+# torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Whichever HIP runtime is loaded first serves the
+# whole process, and two copies cannot both own the GPU: import torch BEFORE libcrt_hip.so is loaded so that the tests
+# that hand torch tensors to the C ABI share one runtime with it.
+try:
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch is plumbing for a few tests only
+    torch = None
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)

@@ -30,6 +30,7 @@ struct HostCounters {
     void sphere() { spheres++; }
     void ray() { rays++; }
     void refold() { refolds++; }
+    void shade() {}
 };
 SceneView host_view(const crt_scene *s, std::vector<Sphere> &spheres)
 {
