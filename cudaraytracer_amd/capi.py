@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrt_hip.so")
+# CRT_LIB: load another build of the same library (A/B runs of kernel variants during tuning)
+LIB_PATH = os.environ.get("CRT_LIB") or os.path.join(_HERE, "libcrt_hip.so")
 
 CRT_OK, CRT_ERR_INVALID, CRT_ERR_IO, CRT_ERR_HIP, CRT_ERR_LIMIT, CRT_ERR_NO_DEVICE = range(6)
 TEX_SOLID, TEX_CHECKER = 0, 1
@@ -40,7 +41,7 @@ class RenderParams(C.Structure):  # crt_render_params
 
 class Stats(C.Structure):  # crt_stats
     _fields_ = [("rays", C.c_uint64), ("nodes", C.c_uint64), ("tri_tests", C.c_uint64), ("sphere_tests", C.c_uint64), ("tie_refolds", C.c_uint64),
-                ("shaded_hits", C.c_uint64), ("kernel_ms", C.c_float), ("reserved", C.c_uint32)]
+                ("shaded_hits", C.c_uint64), ("sched", C.c_uint64 * 10), ("kernel_ms", C.c_float), ("reserved", C.c_uint32)]
 
 
 class SceneInfo(C.Structure):  # crt_scene_info

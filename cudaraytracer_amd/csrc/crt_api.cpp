@@ -5,6 +5,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -146,6 +147,7 @@ struct crt_scene {
     void *d_nodes = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_mats = nullptr, *d_texs = nullptr;
     unsigned long long *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint32_t max_waves = 0; // persistent-grid size: compute units x wave slots
     SceneView view{};
     // staging for host-pointer renders (grow only)
     float *d_stage_rgb = nullptr; size_t stage_rgb_floats = 0;
@@ -301,7 +303,12 @@ extern "C" int crt_scene_commit(crt_scene *s, int device)
     if ((rc = upload(&s->d_spheres, spheres))) return rc;
     if ((rc = upload(&s->d_mats, s->mats))) return rc;
     if ((rc = upload(&s->d_texs, s->texs))) return rc;
-    HIP_TRY(hipMalloc((void **)&s->d_counters, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&s->d_counters, 24 * sizeof(unsigned long long)));
+    {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        s->max_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)std::min(std::max(get_env_int("CRT_WAVES_PER_CU", 32), 1), 64);
+    }
     HIP_TRY(hipEventCreate(&s->ev0));
     HIP_TRY(hipEventCreate(&s->ev1));
 
@@ -416,6 +423,7 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
     ra.tile_rank = p->tile_rank; ra.tile_ranks = p->tile_ranks;
     ra.flags = ((p->flags & CRT_OUT_ACCUM) ? (uint32_t)RA_ACCUM : 0u) | ((p->flags & CRT_OUT_COMPACT) ? (uint32_t)RA_COMPACT : 0u);
     ra.key0 = (uint32_t)p->seed; ra.key1 = (uint32_t)(p->seed >> 32);
+    ra.sched_threshold = (uint32_t)std::min(std::max(get_env_int("CRT_SCHED_THRESHOLD", 40), 1), 64);
 
     const size_t npix = (size_t)p->width * p->height;
     const size_t rgb_floats = (p->flags & CRT_OUT_COMPACT) ? (size_t)crt_compact_floats(p->width, p->height, p->tile_ranks) : npix * 3;
@@ -445,19 +453,20 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
         if (p->tile_ranks > 1) HIP_TRY(hipMemcpyAsync(d_ids, out_ids, npix * sizeof(int), hipMemcpyHostToDevice, stream));
     }
 
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 8 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 24 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    HIP_TRY(launch_render(s->view, *reinterpret_cast<const CameraPOD *>(cam), ra, d_rgb, d_ids, s->d_counters, (p->flags & CRT_COUNT_WORK) != 0, stream));
+    HIP_TRY(launch_render(s->view, *reinterpret_cast<const CameraPOD *>(cam), ra, d_rgb, d_ids, s->d_counters, (p->flags & CRT_COUNT_WORK) != 0, s->max_waves, stream));
     HIP_TRY(hipEventRecord(s->ev1, stream));
 
     if (!rgb_on_device) HIP_TRY(hipMemcpyAsync(out_rgb, d_rgb, rgb_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
     if (out_ids && !ids_on_device) HIP_TRY(hipMemcpyAsync(out_ids, d_ids, npix * sizeof(int), hipMemcpyDeviceToHost, stream));
     if (stats) {
-        unsigned long long c[8];
+        unsigned long long c[24];
         HIP_TRY(hipMemcpyAsync(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         memset(stats, 0, sizeof *stats);
         stats->rays = c[0]; stats->nodes = c[1]; stats->tri_tests = c[2]; stats->sphere_tests = c[3]; stats->tie_refolds = c[4]; stats->shaded_hits = c[5];
+        for (int k = 0; k < 10; k++) stats->sched[k] = c[8 + k];
         float ms = 0.0f;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
         stats->kernel_ms = ms;

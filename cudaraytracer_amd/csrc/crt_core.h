@@ -229,18 +229,19 @@ CRT_HD float reflectance(float cosine, float ri)
 CRT_HD bool scatter(const Material &m, const Texture *texs, f3 ray_d, f3 point, f3 normal, bool front_face, u4 rnd,
                     f3 &attenuation, f3 &new_o, f3 &new_d)
 {
-    if (m.type == MAT_LAMBERTIAN) { // material.h:24-34
-        f3 dir = normal + random_unit_vector(u01(rnd.x), u01(rnd.y));
-        if (length(dir) <= 1e-8f) dir = normal;
-        new_o = point; new_d = dir;
-        attenuation = texture_value(texs[m.tex], point);
-        return true;
-    }
-    if (m.type == MAT_METAL) { // material.h:44-51 (always scatters)
-        const f3 reflected = reflect(ray_d, normal);
-        new_d = axpy(m.param, random_unit_vector(u01(rnd.x), u01(rnd.y)), normalize(reflected));
+    if (m.type == MAT_LAMBERTIAN || m.type == MAT_METAL) {
+        const f3 ruv = random_unit_vector(u01(rnd.x), u01(rnd.y)); // shared by both: the wave evaluates it once
+        if (m.type == MAT_LAMBERTIAN) { // material.h:24-34
+            f3 dir = normal + ruv;
+            if (length(dir) <= 1e-8f) dir = normal;
+            new_d = dir;
+            attenuation = texture_value(texs[m.tex], point);
+        } else { // material.h:44-51 (always scatters)
+            const f3 reflected = reflect(ray_d, normal);
+            new_d = axpy(m.param, ruv, normalize(reflected));
+            attenuation = mk3(m.r, m.g, m.b);
+        }
         new_o = point;
-        attenuation = mk3(m.r, m.g, m.b);
         return true;
     }
     if (m.type == MAT_DIELECTRIC) { // material.h:61-91
@@ -259,6 +260,7 @@ CRT_HD bool scatter(const Material &m, const Texture *texs, f3 ray_d, f3 point, 
     }
     return false;
 }
+CRT_HD bool scatters(const Material &m) { return m.type == MAT_LAMBERTIAN || m.type == MAT_METAL || m.type == MAT_DIELECTRIC; }
 // material.h:10-12, 109-111
 CRT_HD f3 emitted(const Material &m, const Texture *texs, f3 point)
 {
@@ -295,6 +297,32 @@ CRT_HD void camera_ray(const CameraPOD &cam, uint32_t i, uint32_t j, uint32_t pi
     }
     o = origin;
     d = pixel_center - origin;
+}
+
+// The same get_ray cut at Philox block boundaries, for the kernel's scheduler: `block` 0 computes the pixel point
+// (returned in pixel_center) and tests disk draw 0; block k >= 1 tests draws 2k-1 and 2k (draw 10 is taken as is).
+// Returns true when the ray is complete (o, d written); false: call again with the next block.
+CRT_HD bool camera_ray_step(const CameraPOD &cam, uint32_t i, uint32_t j, uint32_t block, u4 r, f3 &pixel_center, f3 &o, f3 &d)
+{
+    bool done = false;
+    float px = 0.0f, py = 0.0f;
+    if (block == 0) {
+        const float ox = fma1(u01(r.x), 0.5f - -0.5f, -0.5f);
+        const float oy = fma1(u01(r.y), 0.5f - -0.5f, -0.5f);
+        pixel_center = axpy(oy + (float)j, cam.pdv, axpy(ox + (float)i, cam.pdu, cam.pixel00));
+        if (cam.defocus_angle <= 0.0f) { o = cam.center; d = pixel_center - cam.center; return true; }
+    } else {
+        px = fma1(u01(r.x), 2.0f, -1.0f); py = fma1(u01(r.y), 2.0f, -1.0f); // draw 2*block-1 <= 9: always tested
+        done = __builtin_sqrtf(fma1(0.0f, 0.0f, fma1(py, py, px * px))) < 1.0f;
+    }
+    if (!done) {
+        px = fma1(u01(r.z), 2.0f, -1.0f); py = fma1(u01(r.w), 2.0f, -1.0f); // draw 2*block
+        done = 2u * block >= 10u || __builtin_sqrtf(fma1(0.0f, 0.0f, fma1(py, py, px * px))) < 1.0f;
+    }
+    if (!done) return false;
+    o = axpy(py, cam.disk_v, axpy(px, cam.disk_u, cam.center));
+    d = pixel_center - o;
+    return true;
 }
 
 } // namespace crt

@@ -11,6 +11,10 @@
 
 namespace crt {
 
+#ifndef CRT_WALK_POLICY
+#define CRT_WALK_POLICY 1
+#endif
+
 struct LdsStack {
     int *col; // &lds[lane], stride 64 ints
     int sp;
@@ -50,18 +54,59 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
+// renderer.h:36-37 + color.h:5-24: average, gamma, store (or the raw sum in accumulate mode)
+__device__ __forceinline__ void store_pixel(const RenderArgs &ra, float *__restrict__ out, int *__restrict__ ids, uint32_t q, uint32_t pixel, f3 col,
+                                            int primary)
+{
+    f3 o = col;
+    if (!(ra.flags & RA_ACCUM)) {
+        o = div3(col, (float)ra.spp);
+        o.x = o.x > 0 ? __builtin_sqrtf(o.x) : 0.0f;
+        o.y = o.y > 0 ? __builtin_sqrtf(o.y) : 0.0f;
+        o.z = o.z > 0 ? __builtin_sqrtf(o.z) : 0.0f;
+    }
+    const size_t idx = (ra.flags & RA_COMPACT) ? (size_t)q : (size_t)pixel;
+    out[3 * idx + 0] = o.x; out[3 * idx + 1] = o.y; out[3 * idx + 2] = o.z;
+    if (ids && ra.ids_sample >= ra.sample_offset && ra.ids_sample - ra.sample_offset < ra.spp) ids[pixel] = primary;
+}
+
+// Lane states of the scheduled kernel
+enum { ST_DONE = 0, ST_NEW = 1, ST_HIT = 2, ST_INNER = 3, ST_LEAF = 4, ST_FETCH = 5 };
+
+__device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
+__device__ __forceinline__ int walk_state(int cur) { return is_inner(cur) ? ST_INNER : (cur < 0 ? ST_LEAF : ST_HIT); }
+
+// render_kernel: one wave64 = one 8x8 pixel tile, one lane = one pixel, the lane's samples summed in sample order.
+//
+// Divergence control.  Paths end after 1..max_depth segments, ~85 % of the segments of the reference scenes never
+// enter the triangle BVH (they miss its root box) and the rest visit ~36 nodes, so lock-step "sample loop / bounce
+// loop / traversal loop" nesting leaves ~80 % of the lanes idle (measured: profiles/r1_v1_nested_loops).  Here every
+// lane is a small state machine
+//     NEW (needs a camera ray) -> INNER / LEAF (walking the BVH) ... -> HIT (walk over: resolve, shade, scatter)
+//     -> INNER/LEAF/HIT (next segment) | NEW (next sample) ... -> DONE
+// and the wave alternates, by 64-bit ballots, between two phases:
+//   A  "shade / regenerate", run when at least `sched_threshold` lanes wait in NEW/HIT (or nobody walks):
+//      HIT lanes resolve their hit, add emission and either end the path or ask for scatter random numbers; NEW lanes
+//      ask for camera random numbers; ONE Philox evaluation serves both kinds; then scatter / camera-ray completion,
+//      the sphere tests and the root-box test start the next walk.  A lane whose path ended becomes NEW and gets its
+//      camera ray in the next phase A (so the wave never evaluates Philox twice per run); a defocus-disk rejection
+//      (utility.h:100-109) likewise retries in the next run with the next Philox block.
+//   B  "walk": one node step for the lanes at a node, or one leaf step for the lanes at a leaf -- whichever group is
+//      larger -- until enough lanes wait for phase A again.
+// A lane's own operation sequence is exactly the sequential one (crt_traverse.h: sample_radiance), so results do
+// not depend on the schedule.
 template <bool COUNT_WORK>
 __global__ __launch_bounds__(64) void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
                                                     int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
     __shared__ int lds_stack[CRT_STACK_DEPTH * 64];
     const uint32_t lane = threadIdx.x;
-    const uint32_t tile = blockIdx.x * ra.tile_ranks + ra.tile_rank;
-    if (tile >= ra.tiles_x * ra.tiles_y) return;
-    const uint32_t tx = tile % ra.tiles_x, ty = tile / ra.tiles_x;
-    const uint32_t i = tx * 8u + (lane & 7u), j = ty * 8u + (lane >> 3);
-    const bool inside = i < ra.width && j < ra.height; // renderer.h:22
-    const uint32_t pixel = j * ra.width + i;            // renderer.h:24
+    // Pixels are handed out dynamically: local pixel index q = 64 * (local tile) + (lane-in-tile), drawn from a
+    // device-wide counter, so a lane that finishes its pixel's samples takes the next unclaimed pixel instead of
+    // idling until the slowest lane of its tile is done.  Each pixel is still computed start to finish by one lane.
+    unsigned int *work = reinterpret_cast<unsigned int *>(counters + 6);
+    const uint32_t NO_PIXEL = 0xFFFFFFFFu;
+    uint32_t q = NO_PIXEL, i = 0, j = 0, pixel = 0;
 
     LdsStack stack;
     stack.col = lds_stack + lane;
@@ -70,27 +115,141 @@ __global__ __launch_bounds__(64) void render_kernel(SceneView sc, CameraPOD cam,
 
     f3 col = mk3(0.0f, 0.0f, 0.0f);
     int primary = -1;
-    if (inside) {
-        for (uint32_t s = 0; s < ra.spp; s++) { // renderer.h:29-32
-            const uint32_t sample = ra.sample_offset + s;
-            int prim;
-            const f3 c = sample_radiance(sc, cam, i, j, pixel, sample, ra.max_depth, ra.key0, ra.key1, stack, cnt, prim);
-            col = col + c;
-            if (sample == ra.ids_sample) primary = prim;
+    const float tmin = 0.001f; // camera.h:68
+
+    int state = ST_FETCH;
+    uint32_t s_idx = 0, depth = 0;
+    int path_prim = -1;
+    Path p;
+    p.o = p.d = p.attenuation = p.color = mk3(0.0f, 0.0f, 0.0f);
+    Search hit;
+    hit.t = FLT_MAX; hit.code = -1; hit.rank = 0; hit.near_tie = false;
+    Trav tv;
+    tv.idir = tv.ood = mk3(0.0f, 0.0f, 0.0f); tv.shift = 0.0f; tv.hi = 0.0f; tv.cur = CRT_BVH_NONE;
+    const int threshold = (int)ra.sched_threshold;
+    uint32_t wc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // schedule counters, lane 0 only (COUNT_WORK)
+
+    for (;;) {
+        const int nready = popc64(__ballot(state == ST_NEW || state == ST_HIT || state == ST_FETCH));
+        const int nwalk = popc64(__ballot(state == ST_INNER || state == ST_LEAF));
+        if (nready + nwalk == 0) break;
+        if (nready >= threshold || nwalk == 0) {
+            // ---- phase A ----
+            if constexpr (COUNT_WORK) {
+                const int nh = popc64(__ballot(state == ST_HIT));
+                if (lane == 0) { wc[0]++; wc[1] += nready; wc[2] += nh; }
+            }
+            bool has_ray = false;
+            if (state == ST_HIT) {
+                const uint32_t sample = ra.sample_offset + s_idx;
+                float t = 0.0f;
+                const int code = resolve_hit(sc, p.o, p.d, tmin, FLT_MAX, hit, t, stack, cnt);
+                bool go_on = false;
+                if (code < 0) { // camera.h:68-71
+                    p.color = mk3(fma1(p.attenuation.x, cam.background.x, p.color.x), fma1(p.attenuation.y, cam.background.y, p.color.y),
+                                  fma1(p.attenuation.z, cam.background.z, p.color.z));
+                } else {
+                    const Surface sf = surface_at(sc, code, p.o, p.d, t);
+                    cnt.shade();
+                    if (depth == 0) path_prim = sf.prim;
+                    const Material m = sc.mats[sf.material];
+                    const f3 e = emitted(m, sc.texs, sf.point); // camera.h:73-74
+                    p.color = mk3(fma1(p.attenuation.x, e.x, p.color.x), fma1(p.attenuation.y, e.y, p.color.y), fma1(p.attenuation.z, e.z, p.color.z));
+                    // camera.h:66,78: the scatter of the last allowed bounce cannot reach the image: not evaluated
+                    if (scatters(m) && depth + 1 < ra.max_depth) {
+                        const u4 r = philox4x32_10(pixel, sample, 1u + depth, 0u, ra.key0, ra.key1);
+                        f3 att, no, nd;
+                        scatter(m, sc.texs, p.d, sf.point, sf.normal, sf.front_face, r, att, no, nd);
+                        p.attenuation = p.attenuation * att; // camera.h:82-83
+                        p.o = no; p.d = nd;
+                        depth++;
+                        go_on = true;
+                    }
+                }
+                if (go_on) {
+                    has_ray = true;
+                } else { // path over: renderer.h:31
+                    col = col + p.color;
+                    if (sample == ra.ids_sample) primary = path_prim;
+                    s_idx++;
+                    state = s_idx < ra.spp ? ST_NEW : ST_FETCH;
+                }
+            }
+            if (state == ST_FETCH) {
+                if (q != NO_PIXEL) store_pixel(ra, out, ids, q, pixel, col, primary);
+                for (;;) {
+                    q = atomicAdd(work, 1u);
+                    if (q >= ra.local_pixels) { q = NO_PIXEL; state = ST_DONE; break; }
+                    const uint32_t tile = (q >> 6) * ra.tile_ranks + ra.tile_rank, l = q & 63u;
+                    i = (tile % ra.tiles_x) * 8u + (l & 7u);
+                    j = (tile / ra.tiles_x) * 8u + (l >> 3);
+                    if (i < ra.width && j < ra.height) { // renderer.h:22
+                        pixel = j * ra.width + i;      // renderer.h:24
+                        s_idx = 0;
+                        col = mk3(0.0f, 0.0f, 0.0f);
+                        primary = -1;
+                        state = ST_NEW;
+                        break;
+                    }
+                    if (ra.flags & RA_COMPACT) { out[3 * (size_t)q + 0] = 0.0f; out[3 * (size_t)q + 1] = 0.0f; out[3 * (size_t)q + 2] = 0.0f; }
+                }
+            }
+            if (state == ST_NEW) {
+                camera_ray(cam, i, j, pixel, ra.sample_offset + s_idx, ra.key0, ra.key1, p.o, p.d);
+                p.attenuation = mk3(1.0f, 1.0f, 1.0f);
+                p.color = mk3(0.0f, 0.0f, 0.0f);
+                depth = 0;
+                path_prim = -1;
+                has_ray = true;
+            }
+            if (has_ray) {
+                cnt.ray();
+                hit.t = FLT_MAX; hit.code = -1; hit.near_tie = false;
+                trav_begin<MODE_CLOSEST>(sc, p.o, p.d, tmin, hit, 0, 0.0f, tv, stack, cnt);
+                state = walk_state(tv.cur);
+            }
+        } else {
+            // ---- phase B ----
+#if CRT_WALK_POLICY == 0
+            for (;;) { // while-while: node steps until every walking lane is at a leaf (or done), then the leaves
+                while (state == ST_INNER) {
+                    if constexpr (COUNT_WORK) { const unsigned long long m_ = __ballot(true); if (lane == (uint32_t)__builtin_ctzll(m_)) { wc[4]++; wc[5] += popc64(m_); } }
+                    trav_inner(sc, tv, stack, cnt);
+                    state = walk_state(tv.cur);
+                }
+                if constexpr (COUNT_WORK) { const int nl = popc64(__ballot(state == ST_LEAF)); if (lane == 0) { wc[6] += nl ? 1 : 0; wc[7] += nl; } }
+                if (state == ST_LEAF) {
+                    trav_leaf<MODE_CLOSEST>(sc, p.o, p.d, tmin, hit, 0, 0.0f, tv, stack, cnt);
+                    state = walk_state(tv.cur);
+                }
+                const int nr = popc64(__ballot(state == ST_NEW || state == ST_HIT || state == ST_FETCH));
+                const int nw = popc64(__ballot(state == ST_INNER || state == ST_LEAF));
+                if (nw == 0 || nr >= threshold) break;
+            }
+#else
+            for (;;) { // one node step or one leaf step, whichever group of lanes is larger
+                const int n_inner = popc64(__ballot(state == ST_INNER));
+                const int n_leaf = popc64(__ballot(state == ST_LEAF));
+                if (n_inner >= n_leaf) {
+                    if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_inner; } }
+                    if (state == ST_INNER) {
+                        trav_inner(sc, tv, stack, cnt);
+                        state = walk_state(tv.cur);
+                    }
+                } else {
+                    if constexpr (COUNT_WORK) { if (lane == 0) { wc[6]++; wc[7] += n_leaf; } }
+                    if (state == ST_LEAF) {
+                        trav_leaf<MODE_CLOSEST>(sc, p.o, p.d, tmin, hit, 0, 0.0f, tv, stack, cnt);
+                        state = walk_state(tv.cur);
+                    }
+                }
+                const int nr = popc64(__ballot(state == ST_NEW || state == ST_HIT || state == ST_FETCH));
+                const int nw = popc64(__ballot(state == ST_INNER || state == ST_LEAF));
+                if (nw == 0 || nr >= threshold) break;
+            }
+#endif
         }
     }
-    if (inside || (ra.flags & RA_COMPACT)) {
-        f3 o = col;
-        if (!(ra.flags & RA_ACCUM)) { // renderer.h:36-37, color.h:5-24
-            o = div3(col, (float)ra.spp);
-            o.x = o.x > 0 ? __builtin_sqrtf(o.x) : 0.0f;
-            o.y = o.y > 0 ? __builtin_sqrtf(o.y) : 0.0f;
-            o.z = o.z > 0 ? __builtin_sqrtf(o.z) : 0.0f;
-        }
-        const size_t idx = (ra.flags & RA_COMPACT) ? ((size_t)blockIdx.x * 64u + lane) : (size_t)pixel;
-        out[3 * idx + 0] = o.x; out[3 * idx + 1] = o.y; out[3 * idx + 2] = o.z;
-    }
-    if (ids && inside && ra.ids_sample >= ra.sample_offset && ra.ids_sample - ra.sample_offset < ra.spp) ids[pixel] = primary;
 
     const uint32_t rays = wave_sum(cnt.rays), refolds = wave_sum(cnt.refolds);
     if (lane == 0) {
@@ -104,6 +263,11 @@ __global__ __launch_bounds__(64) void render_kernel(SceneView sc, CameraPOD cam,
             atomicAdd(&counters[1], (unsigned long long)n);
             atomicAdd(&counters[2], (unsigned long long)t);
             atomicAdd(&counters[3], (unsigned long long)sp);
+        }
+#pragma unroll
+        for (int k = 0; k < 10; k++) {
+            const uint32_t w = wave_sum(wc[k]);
+            if (lane == 0) atomicAdd(&counters[8 + k], (unsigned long long)w);
         }
     }
 }
@@ -135,13 +299,17 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float *__restrict__
 }
 
 hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,
-                         bool count_work, hipStream_t stream)
+                         bool count_work, uint32_t max_waves, hipStream_t stream)
 {
     const uint32_t ntiles = ra.tiles_x * ra.tiles_y;
-    const uint32_t blocks = (ntiles + ra.tile_ranks - 1 - ra.tile_rank) / ra.tile_ranks; // tiles k = b*ranks + rank < ntiles
-    if (blocks == 0) return hipSuccess;
-    if (count_work) hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(64), 0, stream, sc, cam, ra, out, ids, counters);
-    else hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(64), 0, stream, sc, cam, ra, out, ids, counters);
+    const uint32_t local_tiles = (ntiles + ra.tile_ranks - 1 - ra.tile_rank) / ra.tile_ranks; // tiles k = b*ranks + rank < ntiles
+    if (local_tiles == 0) return hipSuccess;
+    RenderArgs a = ra;
+    a.local_pixels = local_tiles * 64u;
+    // persistent waves: enough to fill the device; each lane keeps drawing pixels until the counter runs out
+    const uint32_t blocks = local_tiles < max_waves ? local_tiles : max_waves;
+    if (count_work) hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
+    else hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
     return hipGetLastError();
 }
 

@@ -86,12 +86,33 @@ CRT_HD void offer(Search &s, float t, int code, int rank, int after_rank, float 
     }
 }
 
-// One walk over spheres + BVH.  MODE_CLOSEST: s.t must start at tmax (FLT_MAX).  MODE_NEXT_RANK: only
-// candidates with t <= t_hi and rank > after_rank are considered, s.rank must start at INT_MAX.
-template <int MODE, class Stack, class Counters>
-CRT_HD void walk(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Stack &stack, Counters &cnt)
+// Traversal registers of one lane.  The walk is cut into steps (begin / inner node / leaf) so that the gfx950
+// kernel can interleave lanes that are at different stages (crt_kernels.hip); walk() below strings them together.
+struct Trav {
+    f3 idir, ood; // slab arithmetic: t' = b * idir - ood, origin re-based to the root-box entry
+    float shift;  // t = t' + shift
+    float hi;     // upper pruning bound in re-based time
+    int cur;      // current ref (node >= 0, leaf < 0) or CRT_BVH_NONE when the walk is over
+};
+
+CRT_HD float fast_rcp(float x)
 {
-    // spheres: a short flat list (ground + light in the reference scenes, scene.h:164-165)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
+CRT_HD bool is_inner(int ref) { return (unsigned)ref < (unsigned)CRT_BVH_NONE; }
+
+// Spheres (a short flat list: ground + light in the reference scenes, scene.h:164-165), then the root box.
+// MODE_CLOSEST: s.t must start at tmax (FLT_MAX).  MODE_NEXT_RANK: only candidates with t <= t_hi and
+// rank > after_rank are considered, s.rank must start at INT_MAX.  Leaves tv.cur = CRT_BVH_NONE if no node needs visiting.
+template <int MODE, class Stack, class Counters>
+CRT_HD void trav_begin(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Trav &tv, Stack &stack, Counters &cnt)
+{
+    tv.cur = CRT_BVH_NONE;
     for (uint32_t k = 0; k < sc.nspheres; k++) {
         const Sphere sp = sc.spheres[k];
         float t;
@@ -99,96 +120,106 @@ CRT_HD void walk(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int aft
         if (sphere_t(mk3(sp.cx, sp.cy, sp.cz), sp.radius, o, d, tmin, t)) offer<MODE>(s, t, (int)(sc.ntris + k), sp.rank, after_rank, t_hi);
     }
     if (sc.root_ref == CRT_BVH_NONE) return;
-
     // slab arithmetic for pruning: idir finite, origin re-based to the root box entry so that rounding stays
     // small against the box margin wherever the ray starts.
-    f3 idir = mk3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // (pruning only, so the 1-ulp hardware reciprocal is enough; it never touches a result)
+    f3 idir = mk3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
     if (!(__builtin_fabsf(idir.x) <= 1e30f)) idir.x = __builtin_copysignf(1e30f, d.x);
     if (!(__builtin_fabsf(idir.y) <= 1e30f)) idir.y = __builtin_copysignf(1e30f, d.y);
     if (!(__builtin_fabsf(idir.z) <= 1e30f)) idir.z = __builtin_copysignf(1e30f, d.z);
-    float shift;
-    {
-        const float ax = (sc.root_min.x - o.x) * idir.x, bx = (sc.root_max.x - o.x) * idir.x;
-        const float ay = (sc.root_min.y - o.y) * idir.y, by = (sc.root_max.y - o.y) * idir.y;
-        const float az = (sc.root_min.z - o.z) * idir.z, bz = (sc.root_max.z - o.z) * idir.z;
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-        const float hi = ((MODE == MODE_CLOSEST) ? s.t : t_hi) + CRT_TIE_WINDOW;
-        if (!(tn <= tf && tf >= 0.0f && tn <= hi)) return;
-        shift = __builtin_fmaxf(tn, 0.0f);
-    }
-    const f3 ob = axpy(shift, d, o);
-    const f3 ood = mk3(ob.x * idir.x, ob.y * idir.y, ob.z * idir.z);
-    const float lo = -shift; // t >= 0 in re-based time
-    // upper pruning bound in re-based time
-    float hi = ((MODE == MODE_CLOSEST) ? s.t : t_hi) - shift + CRT_TIE_WINDOW;
-
-    int cur = sc.root_ref;
+    const float ax = (sc.root_min.x - o.x) * idir.x, bx = (sc.root_max.x - o.x) * idir.x;
+    const float ay = (sc.root_min.y - o.y) * idir.y, by = (sc.root_max.y - o.y) * idir.y;
+    const float az = (sc.root_min.z - o.z) * idir.z, bz = (sc.root_max.z - o.z) * idir.z;
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
+    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
+    const float bound = ((MODE == MODE_CLOSEST) ? s.t : t_hi) + CRT_TIE_WINDOW;
+    if (!(tn <= tf && tf >= 0.0f && tn <= bound)) return;
+    tv.shift = __builtin_fmaxf(tn, 0.0f);
+    const f3 ob = axpy(tv.shift, d, o);
+    tv.idir = idir;
+    tv.ood = mk3(ob.x * idir.x, ob.y * idir.y, ob.z * idir.z);
+    tv.hi = ((MODE == MODE_CLOSEST) ? s.t : t_hi) - tv.shift + CRT_TIE_WINDOW;
+    tv.cur = sc.root_ref;
     stack.reset();
-    while (cur != CRT_BVH_NONE) {
-        while ((unsigned)cur < (unsigned)CRT_BVH_NONE) {
-            const q4 *n = sc.nodes + 4 * (size_t)cur;
-            const q4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
-            cnt.node();
-            const float a0x = fma1(n0.x, idir.x, -ood.x), b0x = fma1(n1.x, idir.x, -ood.x);
-            const float a0y = fma1(n0.y, idir.y, -ood.y), b0y = fma1(n1.y, idir.y, -ood.y);
-            const float a0z = fma1(n0.z, idir.z, -ood.z), b0z = fma1(n1.z, idir.z, -ood.z);
-            const float a1x = fma1(n2.x, idir.x, -ood.x), b1x = fma1(n3.x, idir.x, -ood.x);
-            const float a1y = fma1(n2.y, idir.y, -ood.y), b1y = fma1(n3.y, idir.y, -ood.y);
-            const float a1z = fma1(n2.z, idir.z, -ood.z), b1z = fma1(n3.z, idir.z, -ood.z);
-            const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0x, b0x), __builtin_fminf(a0y, b0y)),
-                                              __builtin_fmaxf(__builtin_fminf(a0z, b0z), lo));
-            const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0x, b0x), __builtin_fmaxf(a0y, b0y)),
-                                              __builtin_fminf(__builtin_fmaxf(a0z, b0z), hi));
-            const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a1x, b1x), __builtin_fminf(a1y, b1y)),
-                                              __builtin_fmaxf(__builtin_fminf(a1z, b1z), lo));
-            const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a1x, b1x), __builtin_fmaxf(a1y, b1y)),
-                                              __builtin_fminf(__builtin_fmaxf(a1z, b1z), hi));
-            const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-            const int r0 = f2i(n0.w), r1 = f2i(n1.w);
-            if (h0 && h1) {
-                const bool swap = tn1 < tn0;
-                stack.push(swap ? r0 : r1);
-                cur = swap ? r1 : r0;
-            } else if (h0) {
-                cur = r0;
-            } else if (h1) {
-                cur = r1;
-            } else {
-                cur = stack.pop();
-            }
-        }
-        if (cur < 0) {
-            const uint32_t bits = (uint32_t)~cur;
-            const uint32_t first = bits >> 3, count = (bits & 7u) + 1u;
-            for (uint32_t k = 0; k < count; k++) {
-                const q4 *tp = sc.tris + 3 * (size_t)(first + k);
-                const q4 ta = tp[0], tb = tp[1], tc = tp[2];
-                float t;
-                cnt.tri();
-                if (triangle_t(mk3(ta.x, ta.y, ta.z), mk3(tb.x, tb.y, tb.z), mk3(tc.x, tc.y, tc.z), o, d, tmin, t)) {
-                    offer<MODE>(s, t, (int)(first + k), f2i(tb.w), after_rank, t_hi);
-                    if (MODE == MODE_CLOSEST) hi = s.t - shift + CRT_TIE_WINDOW;
-                }
-            }
-            cur = stack.pop();
-        }
+}
+
+// One two-child node: both child boxes, near child next, far child pushed.  Requires is_inner(tv.cur).
+template <class Stack, class Counters>
+CRT_HD void trav_inner(const SceneView &sc, Trav &tv, Stack &stack, Counters &cnt)
+{
+    const q4 *n = sc.nodes + 4 * (size_t)tv.cur;
+    const q4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+    cnt.node();
+    const f3 idir = tv.idir, ood = tv.ood;
+    const float lo = -tv.shift, hi = tv.hi; // t >= 0 in re-based time
+    const float a0x = fma1(n0.x, idir.x, -ood.x), b0x = fma1(n1.x, idir.x, -ood.x);
+    const float a0y = fma1(n0.y, idir.y, -ood.y), b0y = fma1(n1.y, idir.y, -ood.y);
+    const float a0z = fma1(n0.z, idir.z, -ood.z), b0z = fma1(n1.z, idir.z, -ood.z);
+    const float a1x = fma1(n2.x, idir.x, -ood.x), b1x = fma1(n3.x, idir.x, -ood.x);
+    const float a1y = fma1(n2.y, idir.y, -ood.y), b1y = fma1(n3.y, idir.y, -ood.y);
+    const float a1z = fma1(n2.z, idir.z, -ood.z), b1z = fma1(n3.z, idir.z, -ood.z);
+    const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0x, b0x), __builtin_fminf(a0y, b0y)),
+                                      __builtin_fmaxf(__builtin_fminf(a0z, b0z), lo));
+    const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0x, b0x), __builtin_fmaxf(a0y, b0y)),
+                                      __builtin_fminf(__builtin_fmaxf(a0z, b0z), hi));
+    const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a1x, b1x), __builtin_fminf(a1y, b1y)),
+                                      __builtin_fmaxf(__builtin_fminf(a1z, b1z), lo));
+    const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a1x, b1x), __builtin_fmaxf(a1y, b1y)),
+                                      __builtin_fminf(__builtin_fmaxf(a1z, b1z), hi));
+    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+    const int r0 = f2i(n0.w), r1 = f2i(n1.w);
+    if (h0 && h1) {
+        const bool swap = tn1 < tn0;
+        stack.push(swap ? r0 : r1);
+        tv.cur = swap ? r1 : r0;
+    } else if (h0) {
+        tv.cur = r0;
+    } else if (h1) {
+        tv.cur = r1;
+    } else {
+        tv.cur = stack.pop();
     }
 }
 
-// world->hit(ray, Interval(tmin, FLT_MAX), rec) (camera.h:68 -> hittable_list.h:17-63): returns the winning
-// primitive code (-1 = miss) and its t.
-template <class Stack, class Counters>
-CRT_HD int closest_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float &t_hit, Stack &stack, Counters &cnt)
+// One leaf: its 1..8 triangle slots.  Requires tv.cur < 0.
+template <int MODE, class Stack, class Counters>
+CRT_HD void trav_leaf(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Trav &tv, Stack &stack, Counters &cnt)
 {
-    cnt.ray();
-    Search s;
-    s.t = tmax; s.code = -1; s.rank = 0; s.near_tie = false;
-    walk<MODE_CLOSEST>(sc, o, d, tmin, s, 0, 0.0f, stack, cnt);
+    const uint32_t bits = (uint32_t)~tv.cur;
+    const uint32_t first = bits >> 3, count = (bits & 7u) + 1u;
+    for (uint32_t k = 0; k < count; k++) {
+        const q4 *tp = sc.tris + 3 * (size_t)(first + k);
+        const q4 ta = tp[0], tb = tp[1], tc = tp[2];
+        float t;
+        cnt.tri();
+        if (triangle_t(mk3(ta.x, ta.y, ta.z), mk3(tb.x, tb.y, tb.z), mk3(tc.x, tc.y, tc.z), o, d, tmin, t)) {
+            offer<MODE>(s, t, (int)(first + k), f2i(tb.w), after_rank, t_hi);
+            if (MODE == MODE_CLOSEST) tv.hi = s.t - tv.shift + CRT_TIE_WINDOW;
+        }
+    }
+    tv.cur = stack.pop();
+}
+
+// One whole walk over spheres + BVH.
+template <int MODE, class Stack, class Counters>
+CRT_HD void walk(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Stack &stack, Counters &cnt)
+{
+    Trav tv;
+    trav_begin<MODE>(sc, o, d, tmin, s, after_rank, t_hi, tv, stack, cnt);
+    while (tv.cur != CRT_BVH_NONE) {
+        while (is_inner(tv.cur)) trav_inner(sc, tv, stack, cnt);
+        if (tv.cur < 0) trav_leaf<MODE>(sc, o, d, tmin, s, after_rank, t_hi, tv, stack, cnt);
+    }
+}
+
+// After a MODE_CLOSEST walk: the reference's winner.  Fast path when no two candidates came within the tie
+// window; otherwise the fold in reference leaf order (one MODE_NEXT_RANK walk per candidate in the window).
+template <class Stack, class Counters>
+CRT_HD int resolve_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, const Search &s, float &t_hit, Stack &stack, Counters &cnt)
+{
     if (s.code < 0) return -1;
     // sphere.h:36 / triangle.h:75 also bound t by the caller's tmax (FLT_MAX everywhere in the reference)
     if (!s.near_tie) { t_hit = s.t; return s.t <= tmax ? s.code : -1; }
-    // tie path: fold the window [t_min, t_min + W] in rank order with the reference's comparisons
     cnt.refold();
     const float t_hi = s.t + CRT_TIE_WINDOW;
     float closest = tmax;
@@ -204,6 +235,18 @@ CRT_HD int closest_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, 
     }
     t_hit = closest;
     return win;
+}
+
+// world->hit(ray, Interval(tmin, FLT_MAX), rec) (camera.h:68 -> hittable_list.h:17-63): returns the winning
+// primitive code (-1 = miss) and its t.
+template <class Stack, class Counters>
+CRT_HD int closest_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float &t_hit, Stack &stack, Counters &cnt)
+{
+    cnt.ray();
+    Search s;
+    s.t = tmax; s.code = -1; s.rank = 0; s.near_tie = false;
+    walk<MODE_CLOSEST>(sc, o, d, tmin, s, 0, 0.0f, stack, cnt);
+    return resolve_hit(sc, o, d, tmin, tmax, s, t_hit, stack, cnt);
 }
 
 // Hit record of the winning primitive: point, face-forward normal, material, primitive id
@@ -232,38 +275,51 @@ CRT_HD Surface surface_at(const SceneView &sc, int code, f3 o, f3 d, float t)
     return r;
 }
 
+// One iteration of Camera::ray_color's loop body after world->hit() (camera.h:68-83): `code`/`t` are the hit (code < 0:
+// miss).  Updates colour / attenuation / ray; returns false when the path ends (miss, no scatter).
+struct Path { f3 o, d, attenuation, color; };
+
+template <class Counters>
+CRT_HD bool path_bounce(const SceneView &sc, const CameraPOD &cam, Path &p, int code, float t, uint32_t depth, uint32_t pixel, uint32_t sample,
+                        uint32_t k0, uint32_t k1, Counters &cnt, int &primary_prim)
+{
+    if (code < 0) {
+        p.color = mk3(fma1(p.attenuation.x, cam.background.x, p.color.x), fma1(p.attenuation.y, cam.background.y, p.color.y),
+                      fma1(p.attenuation.z, cam.background.z, p.color.z));
+        return false;
+    }
+    const Surface sf = surface_at(sc, code, p.o, p.d, t);
+    cnt.shade();
+    if (depth == 0) primary_prim = sf.prim;
+    const Material m = sc.mats[sf.material];
+    const f3 e = emitted(m, sc.texs, sf.point);
+    p.color = mk3(fma1(p.attenuation.x, e.x, p.color.x), fma1(p.attenuation.y, e.y, p.color.y), fma1(p.attenuation.z, e.z, p.color.z));
+    if (!scatters(m)) return false; // material.h:14-16
+    const u4 rnd = philox4x32_10(pixel, sample, 1u + depth, 0u, k0, k1);
+    f3 att, no, nd;
+    if (!scatter(m, sc.texs, p.d, sf.point, sf.normal, sf.front_face, rnd, att, no, nd)) return false;
+    p.attenuation = p.attenuation * att;
+    p.o = no; p.d = nd;
+    return true;
+}
+
 // Camera::ray_color (camera.h:60-87) for sample `sample` of pixel (i, j); primary_prim receives the id of
-// the first hit (-1 = miss).
+// the first hit (-1 = miss).  Sequential form (host single-stepper; the kernel schedules the same steps per lane).
 template <class Stack, class Counters>
 CRT_HD f3 sample_radiance(const SceneView &sc, const CameraPOD &cam, uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample,
                           uint32_t max_depth, uint32_t k0, uint32_t k1, Stack &stack, Counters &cnt, int &primary_prim)
 {
-    f3 o, d;
-    camera_ray(cam, i, j, pixel, sample, k0, k1, o, d);
-    f3 attenuation = mk3(1.0f, 1.0f, 1.0f);
-    f3 color = mk3(0.0f, 0.0f, 0.0f);
+    Path p;
+    camera_ray(cam, i, j, pixel, sample, k0, k1, p.o, p.d);
+    p.attenuation = mk3(1.0f, 1.0f, 1.0f);
+    p.color = mk3(0.0f, 0.0f, 0.0f);
     primary_prim = -1;
     for (uint32_t depth = 0; depth < max_depth; depth++) {
-        float t;
-        const int code = closest_hit(sc, o, d, 0.001f, FLT_MAX, t, stack, cnt);
-        if (code < 0) {
-            color = mk3(fma1(attenuation.x, cam.background.x, color.x), fma1(attenuation.y, cam.background.y, color.y),
-                        fma1(attenuation.z, cam.background.z, color.z));
-            break;
-        }
-        const Surface sf = surface_at(sc, code, o, d, t);
-        cnt.shade();
-        if (depth == 0) primary_prim = sf.prim;
-        const Material m = sc.mats[sf.material];
-        const f3 e = emitted(m, sc.texs, sf.point);
-        color = mk3(fma1(attenuation.x, e.x, color.x), fma1(attenuation.y, e.y, color.y), fma1(attenuation.z, e.z, color.z));
-        const u4 rnd = philox4x32_10(pixel, sample, 1u + depth, 0u, k0, k1);
-        f3 att, no, nd;
-        if (!scatter(m, sc.texs, d, sf.point, sf.normal, sf.front_face, rnd, att, no, nd)) break;
-        attenuation = attenuation * att;
-        o = no; d = nd;
+        float t = 0.0f;
+        const int code = closest_hit(sc, p.o, p.d, 0.001f, FLT_MAX, t, stack, cnt);
+        if (!path_bounce(sc, cam, p, code, t, depth, pixel, sample, k0, k1, cnt, primary_prim)) break;
     }
-    return color;
+    return p.color;
 }
 
 } // namespace crt

@@ -127,6 +127,8 @@ typedef struct crt_stats {
     uint64_t sphere_tests;  /* 32-byte sphere records tested    (CRT_COUNT_WORK)                            */
     uint64_t tie_refolds;   /* rays that took the exact reference-order tie fold                            */
     uint64_t shaded_hits;   /* rays that hit something and were shaded (CRT_COUNT_WORK)                     */
+    uint64_t sched[10];     /* schedule counters (CRT_COUNT_WORK): for each lane state NEW, BEGIN, INNER, LEAF, HIT the
+                               number of wave steps run for it and the lanes that took part                          */
     float kernel_ms;        /* hipEvent time of the render kernel on `stream`                               */
     uint32_t reserved;
 } crt_stats;
