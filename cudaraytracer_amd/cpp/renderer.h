@@ -1,0 +1,32 @@
+// renderer.h -- reference: class Renderer (renderer.h:7-16, 48-73).  tx, ty are accepted for source compatibility; the
+// library always works on 8x8 tiles = one wave64 (which is also what the reference's main passes, kernel.cu:50-51).
+// No per-pixel RNG state is allocated: the Philox streams are keyed on (pixel, sample, bounce).
+#pragma once
+
+#include "camera.h"
+
+class Renderer {
+public:
+    Renderer(uint32_t width, uint32_t height, uint16_t tx, uint16_t ty, uint32_t spp) : m_width(width), m_height(height), m_samples_per_pixel(spp)
+    {
+        (void)tx; (void)ty;
+        std::clog << "- Renderer Initialized" << std::endl; // renderer.h:61
+    }
+    uint32_t max_depth = 10;  // camera.h:66
+    uint64_t seed = 1984;     // renderer.h:45
+    crt_stats last_stats{};
+
+    // framebuffer: width*height vec3, host memory (the reference passes managed memory, kernel.cu:60) or a HIP device pointer
+    void launch_kernel_render(vec3 *framebuffer, Camera **d_camera, Hittable **d_world)
+    {
+        std::clog << "- Renderering" << std::endl; // renderer.h:65
+        crt_render_params p{};
+        p.width = m_width; p.height = m_height; p.spp = m_samples_per_pixel; p.max_depth = max_depth; p.seed = seed;
+        p.tile_rank = 0; p.tile_ranks = 1;
+        checkCrtErrors(crt_render((*d_world)->scene, &(*d_camera)->pod, &p, &framebuffer[0].x, nullptr, &last_stats));
+    }
+
+private:
+    uint32_t m_width, m_height;
+    uint32_t m_samples_per_pixel;
+};

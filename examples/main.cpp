@@ -1,0 +1,46 @@
+// examples/main.cpp -- the reference's driver flow (kernel.cu:44-103: camera -> scene -> renderer -> render -> export ->
+// free) written against the drop-in headers.  Own code; build:
+//   g++ -O2 -std=c++17 examples/main.cpp -Lcudaraytracer_amd -lcrt_hip -Wl,-rpath,$PWD/cudaraytracer_amd -o crt_demo
+//   ./crt_demo [model.obj] [width] [height] [spp]
+#include <chrono>
+#include <cmath>
+#include <iostream>
+
+#include "../cudaraytracer_amd/cpp/renderer.h"
+#include "../cudaraytracer_amd/cpp/scene.h"
+
+int main(int argc, char **argv)
+{
+    const float ASPECT_RATIO = 16.0f / 9.0f;
+    const std::string model = argc > 1 ? argv[1] : "models/cat.obj";
+    const uint32_t IMAGE_WIDTH = argc > 2 ? (uint32_t)atoi(argv[2]) : 1000, IMAGE_HEIGHT = argc > 3 ? (uint32_t)atoi(argv[3]) : 1000;
+    const uint32_t spp = argc > 4 ? (uint32_t)atoi(argv[4]) : 10, tx = 8, ty = 8;
+    std::cerr << "Rendering a " << IMAGE_WIDTH << "x" << IMAGE_HEIGHT << " image with " << spp << " samples per pixel in " << tx << "x" << ty << " blocks.\n";
+
+    std::vector<vec3> framebuffer((size_t)IMAGE_WIDTH * IMAGE_HEIGHT);
+
+    // init_camera (kernel.cu:30-42)
+    vec3 look_from(8.f, 5.f, -6.0f), look_at(-4, 0, 4), vup(0, 1, 0);
+    const float focus_distance = std::sqrt(look_from.x * look_from.x + look_from.y * look_from.y + look_from.z * look_from.z);
+    Camera *camera = new Camera(IMAGE_WIDTH, look_from, look_at, vup, 25.0f, ASPECT_RATIO, 0.6f, focus_distance);
+    Camera **d_camera = &camera;
+
+    Hittable *world = nullptr;
+    Hittable **d_world = &world;
+    Scene scene;
+    scene.load_models({ model });
+    scene.launch_triangles_scene(d_world);
+    std::clog << "- Scene Created\n";
+
+    Renderer renderer(IMAGE_WIDTH, IMAGE_HEIGHT, tx, ty, spp);
+    const auto start = std::chrono::steady_clock::now();
+    renderer.launch_kernel_render(framebuffer.data(), d_camera, d_world);
+    const double timer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+    std::cerr << "\nRender time: " << timer_seconds << " seconds (kernel " << renderer.last_stats.kernel_ms << " ms, " << renderer.last_stats.rays
+              << " rays).\n";
+
+    export_framebuffer_to_ppm(framebuffer.data(), IMAGE_WIDTH, IMAGE_HEIGHT, "output.ppm");
+    delete world;   // free_world<<<1,1>>> (kernel.cu:25-28,93)
+    delete camera;
+    return 0;
+}
