@@ -414,6 +414,8 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
     if (p->width == 0 || p->height == 0 || p->spp == 0) return fail(CRT_ERR_INVALID, "crt_render: empty frame or zero samples");
     if (p->tile_ranks == 0 || p->tile_rank >= p->tile_ranks) return fail(CRT_ERR_INVALID, "crt_render: tile_rank must be < tile_ranks");
     if ((uint64_t)p->width * p->height > (1ull << 31)) return fail(CRT_ERR_LIMIT, "crt_render: more than 2^31 pixels");
+    if (p->width > 65535u || p->height > 65535u || p->spp > 65535u || p->max_depth > 255u)
+        return fail(CRT_ERR_LIMIT, "crt_render: width, height, spp must be <= 65535 and max_depth <= 255 (packed lane state)");
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t stream = (hipStream_t)p->stream;
 

@@ -11,21 +11,19 @@
 
 namespace crt {
 
-#ifndef CRT_WALK_POLICY
-#define CRT_WALK_POLICY 1
+#ifndef CRT_EXP_TWO_PHILOX
+#define CRT_EXP_TWO_PHILOX 1
 #endif
 
+// Per-lane traversal stack: an LDS column (stack[level][lane]: bank = lane, conflict free).  Level 0 holds the
+// CRT_BVH_NONE sentinel for the whole kernel, so pop() needs no empty check: popping it ends the walk.
 struct LdsStack {
-    int *col; // &lds[lane], stride 64 ints
-    int sp;
-    __device__ __forceinline__ void reset() { sp = 0; }
-    __device__ __forceinline__ void push(int v) { col[sp * 64] = v; sp++; }
-    __device__ __forceinline__ int pop()
-    {
-        if (sp == 0) return CRT_BVH_NONE;
-        sp--;
-        return col[sp * 64];
-    }
+    int *top; // next free slot of this lane's column (stride 64 ints)
+    int *base;
+    __device__ __forceinline__ void init(int *column) { column[0] = CRT_BVH_NONE; base = column + 64; top = base; }
+    __device__ __forceinline__ void reset() { top = base; }
+    __device__ __forceinline__ void push(int v) { *top = v; top += 64; }
+    __device__ __forceinline__ int pop() { top -= 64; return *top; }
 };
 
 struct RegCounters {
@@ -70,56 +68,53 @@ __device__ __forceinline__ void store_pixel(const RenderArgs &ra, float *__restr
     if (ids && ra.ids_sample >= ra.sample_offset && ra.ids_sample - ra.sample_offset < ra.spp) ids[pixel] = primary;
 }
 
-// Lane states of the scheduled kernel
-enum { ST_DONE = 0, ST_NEW = 1, ST_HIT = 2, ST_INNER = 3, ST_LEAF = 4, ST_FETCH = 5 };
-
 __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
-__device__ __forceinline__ int walk_state(int cur) { return is_inner(cur) ? ST_INNER : (cur < 0 ? ST_LEAF : ST_HIT); }
 
-// render_kernel: one wave64 = one 8x8 pixel tile, one lane = one pixel, the lane's samples summed in sample order.
+// Lane phases while not walking (a lane walks the BVH iff tv.cur != CRT_BVH_NONE)
+enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
+
+// render_kernel: one wave64 per workgroup, persistent.  A lane computes a pixel start to finish (its samples summed in
+// sample order, renderer.h:28-32, so the float sum is the reference's whatever the partition) and takes pixels from a
+// device-wide counter in 8x8-tile order (q = 64 * tile + lane-in-tile), so a lane that finishes its pixel does not wait
+// for the slowest lane of its tile.
 //
-// Divergence control.  Paths end after 1..max_depth segments, ~85 % of the segments of the reference scenes never
-// enter the triangle BVH (they miss its root box) and the rest visit ~36 nodes, so lock-step "sample loop / bounce
-// loop / traversal loop" nesting leaves ~80 % of the lanes idle (measured: profiles/r1_v1_nested_loops).  Here every
-// lane is a small state machine
-//     NEW (needs a camera ray) -> INNER / LEAF (walking the BVH) ... -> HIT (walk over: resolve, shade, scatter)
-//     -> INNER/LEAF/HIT (next segment) | NEW (next sample) ... -> DONE
+// Divergence control.  Paths end after 1..max_depth segments; 58 % of the segments of the headline scene never enter
+// the triangle BVH (they miss its root box), the others walk 14 steps on average with a long tail.  Lock-step "sample
+// loop / bounce loop / traversal loop" nesting leaves ~80 % of the lanes idle (profiles/r1_v1_nested_loops).  Here
+// every lane is a small state machine
+//     FETCH (needs a pixel) -> NEW (needs a camera ray) -> walking -> HIT (walk over: resolve, shade, scatter) -> ...
 // and the wave alternates, by 64-bit ballots, between two phases:
-//   A  "shade / regenerate", run when at least `sched_threshold` lanes wait in NEW/HIT (or nobody walks):
-//      HIT lanes resolve their hit, add emission and either end the path or ask for scatter random numbers; NEW lanes
-//      ask for camera random numbers; ONE Philox evaluation serves both kinds; then scatter / camera-ray completion,
-//      the sphere tests and the root-box test start the next walk.  A lane whose path ended becomes NEW and gets its
-//      camera ray in the next phase A (so the wave never evaluates Philox twice per run); a defocus-disk rejection
-//      (utility.h:100-109) likewise retries in the next run with the next Philox block.
-//   B  "walk": one node step for the lanes at a node, or one leaf step for the lanes at a leaf -- whichever group is
-//      larger -- until enough lanes wait for phase A again.
-// A lane's own operation sequence is exactly the sequential one (crt_traverse.h: sample_radiance), so results do
-// not depend on the schedule.
+//   A  "shade", run when at least `sched_threshold` lanes are not walking (or nobody walks): HIT lanes resolve their
+//      hit, add emission and end the path or ask for scatter random numbers; finished pixels are stored and new ones
+//      fetched; NEW lanes ask for camera random numbers; ONE Philox evaluation serves both kinds; then scatter or
+//      camera ray, the sphere tests and the root-box test start the next walk.  A defocus-disk rejection
+//      (utility.h:100-109) retries in the next run with the next Philox block.
+//   B  "walk": one node step for the lanes at a node or one leaf step for the lanes at a leaf, whichever group is
+//      larger, until enough lanes wait for phase A again.
+// A lane's own operation sequence is exactly the sequential one (crt_traverse.h: sample_radiance), so results do not
+// depend on the schedule.  (Two pixel contexts per lane were tried and measured slower: DESIGN.md section 7.)
 template <bool COUNT_WORK>
 __global__ __launch_bounds__(64) void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
                                                     int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
-    __shared__ int lds_stack[CRT_STACK_DEPTH * 64];
+    __shared__ int lds_stack[(CRT_STACK_DEPTH + 1) * 64];
     const uint32_t lane = threadIdx.x;
-    // Pixels are handed out dynamically: local pixel index q = 64 * (local tile) + (lane-in-tile), drawn from a
-    // device-wide counter, so a lane that finishes its pixel's samples takes the next unclaimed pixel instead of
-    // idling until the slowest lane of its tile is done.  Each pixel is still computed start to finish by one lane.
     unsigned int *work = reinterpret_cast<unsigned int *>(counters + 6);
     const uint32_t NO_PIXEL = 0xFFFFFFFFu;
-    uint32_t q = NO_PIXEL, i = 0, j = 0, pixel = 0;
-
-    LdsStack stack;
-    stack.col = lds_stack + lane;
-    stack.sp = 0;
-    typename std::conditional<COUNT_WORK, RegCounters, RayCounters>::type cnt;
-
-    f3 col = mk3(0.0f, 0.0f, 0.0f);
-    int primary = -1;
     const float tmin = 0.001f; // camera.h:68
 
-    int state = ST_FETCH;
+    LdsStack stack;
+    stack.init(lds_stack + lane);
+    typename std::conditional<COUNT_WORK, RegCounters, RayCounters>::type cnt;
+
+    uint32_t q = NO_PIXEL, i = 0, j = 0, pixel = 0;
+    f3 col = mk3(0.0f, 0.0f, 0.0f);
+    int primary = -1, path_prim = -1;
+    int phase = P_FETCH;
     uint32_t s_idx = 0, depth = 0;
-    int path_prim = -1;
+#if !CRT_EXP_TWO_PHILOX
+    uint32_t cam_block = 0;
+#endif
     Path p;
     p.o = p.d = p.attenuation = p.color = mk3(0.0f, 0.0f, 0.0f);
     Search hit;
@@ -130,124 +125,135 @@ __global__ __launch_bounds__(64) void render_kernel(SceneView sc, CameraPOD cam,
     uint32_t wc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // schedule counters, lane 0 only (COUNT_WORK)
 
     for (;;) {
-        const int nready = popc64(__ballot(state == ST_NEW || state == ST_HIT || state == ST_FETCH));
-        const int nwalk = popc64(__ballot(state == ST_INNER || state == ST_LEAF));
+        const bool walking = tv.cur != CRT_BVH_NONE;
+        const int nwalk = popc64(__ballot(walking));
+        const int nready = popc64(__ballot(!walking && phase != P_DONE));
         if (nready + nwalk == 0) break;
         if (nready >= threshold || nwalk == 0) {
-            // ---- phase A ----
-            if constexpr (COUNT_WORK) {
-                const int nh = popc64(__ballot(state == ST_HIT));
-                if (lane == 0) { wc[0]++; wc[1] += nready; wc[2] += nh; }
-            }
-            bool has_ray = false;
-            if (state == ST_HIT) {
-                const uint32_t sample = ra.sample_offset + s_idx;
-                float t = 0.0f;
-                const int code = resolve_hit(sc, p.o, p.d, tmin, FLT_MAX, hit, t, stack, cnt);
-                bool go_on = false;
-                if (code < 0) { // camera.h:68-71
-                    p.color = mk3(fma1(p.attenuation.x, cam.background.x, p.color.x), fma1(p.attenuation.y, cam.background.y, p.color.y),
-                                  fma1(p.attenuation.z, cam.background.z, p.color.z));
-                } else {
-                    const Surface sf = surface_at(sc, code, p.o, p.d, t);
-                    cnt.shade();
-                    if (depth == 0) path_prim = sf.prim;
-                    const Material m = sc.mats[sf.material];
-                    const f3 e = emitted(m, sc.texs, sf.point); // camera.h:73-74
-                    p.color = mk3(fma1(p.attenuation.x, e.x, p.color.x), fma1(p.attenuation.y, e.y, p.color.y), fma1(p.attenuation.z, e.z, p.color.z));
-                    // camera.h:66,78: the scatter of the last allowed bounce cannot reach the image: not evaluated
-                    if (scatters(m) && depth + 1 < ra.max_depth) {
-                        const u4 r = philox4x32_10(pixel, sample, 1u + depth, 0u, ra.key0, ra.key1);
+            // ================================ phase A ================================
+            if constexpr (COUNT_WORK) { if (lane == 0) { wc[0]++; wc[1] += nready; } }
+            if (!walking && phase != P_DONE) {
+                bool want_scatter = false;
+                Surface sf;
+                sf.point = sf.normal = mk3(0.0f, 0.0f, 0.0f); sf.front_face = false; sf.material = 0; sf.prim = -1;
+                Material m;
+                m.type = MAT_DIFFUSE_LIGHT; m.r = m.g = m.b = m.param = 0.0f; m.tex = 0; m.pad0 = m.pad1 = 0;
+                if (phase == P_HIT) {
+                    float t = 0.0f;
+                    const int code = resolve_hit(sc, p.o, p.d, tmin, FLT_MAX, hit, t, stack, cnt);
+                    if (code < 0) { // camera.h:68-71
+                        p.color = mk3(fma1(p.attenuation.x, cam.background.x, p.color.x), fma1(p.attenuation.y, cam.background.y, p.color.y),
+                                      fma1(p.attenuation.z, cam.background.z, p.color.z));
+                    } else {
+                        sf = surface_at(sc, code, p.o, p.d, t);
+                        cnt.shade();
+                        if (depth == 0) path_prim = sf.prim;
+                        m = sc.mats[sf.material];
+                        const f3 e = emitted(m, sc.texs, sf.point); // camera.h:73-74
+                        p.color = mk3(fma1(p.attenuation.x, e.x, p.color.x), fma1(p.attenuation.y, e.y, p.color.y), fma1(p.attenuation.z, e.z, p.color.z));
+                        // camera.h:66,78: the scatter of the last allowed bounce cannot reach the image: not evaluated
+                        want_scatter = scatters(m) && depth + 1 < ra.max_depth;
+                    }
+                    if (!want_scatter) { // path over: renderer.h:31
+                        col = col + p.color;
+                        if (ra.sample_offset + s_idx == ra.ids_sample) primary = path_prim;
+                        s_idx++;
+#if !CRT_EXP_TWO_PHILOX
+                        cam_block = 0;
+#endif
+                        phase = s_idx < ra.spp ? P_NEW : P_FETCH;
+                    }
+                }
+                if (phase == P_FETCH) {
+                    if (q != NO_PIXEL) store_pixel(ra, out, ids, q, pixel, col, primary);
+                    for (;;) {
+                        q = atomicAdd(work, 1u);
+                        if (q >= ra.local_pixels) { q = NO_PIXEL; phase = P_DONE; break; }
+                        const uint32_t tile = (q >> 6) * ra.tile_ranks + ra.tile_rank, l = q & 63u;
+                        i = (tile % ra.tiles_x) * 8u + (l & 7u);
+                        j = (tile / ra.tiles_x) * 8u + (l >> 3);
+                        if (i < ra.width && j < ra.height) { // renderer.h:22
+                            pixel = j * ra.width + i;      // renderer.h:24
+                            s_idx = 0;
+#if !CRT_EXP_TWO_PHILOX
+                            cam_block = 0;
+#endif
+                            col = mk3(0.0f, 0.0f, 0.0f);
+                            primary = -1;
+                            phase = P_NEW;
+                            break;
+                        }
+                        if (ra.flags & RA_COMPACT) { out[3 * (size_t)q + 0] = 0.0f; out[3 * (size_t)q + 1] = 0.0f; out[3 * (size_t)q + 2] = 0.0f; }
+                    }
+                }
+                bool has_ray = false;
+#if CRT_EXP_TWO_PHILOX
+                if (want_scatter) {
+                    const u4 r = philox4x32_10(pixel, ra.sample_offset + s_idx, 1u + depth, 0u, ra.key0, ra.key1);
+                    f3 att, no, nd;
+                    scatter(m, sc.texs, p.d, sf.point, sf.normal, sf.front_face, r, att, no, nd);
+                    p.attenuation = p.attenuation * att; // camera.h:82-83
+                    p.o = no; p.d = nd;
+                    depth++;
+                    has_ray = true;
+                }
+                if (phase == P_NEW) {
+                    camera_ray(cam, i, j, pixel, ra.sample_offset + s_idx, ra.key0, ra.key1, p.o, p.d);
+                    p.attenuation = mk3(1.0f, 1.0f, 1.0f);
+                    p.color = mk3(0.0f, 0.0f, 0.0f);
+                    depth = 0;
+                    path_prim = -1;
+                    has_ray = true;
+                }
+#else
+                if (want_scatter || phase == P_NEW) {
+                    const bool is_cam = !want_scatter;
+                    const u4 r = philox4x32_10(pixel, ra.sample_offset + s_idx, is_cam ? 0u : 1u + depth, is_cam ? cam_block : 0u, ra.key0, ra.key1);
+                    if (is_cam) {
+                        f3 pc = p.d; // between defocus-disk retries the pixel point is parked in p.d
+                        if (camera_ray_step(cam, i, j, cam_block, r, pc, p.o, p.d)) {
+                            p.attenuation = mk3(1.0f, 1.0f, 1.0f);
+                            p.color = mk3(0.0f, 0.0f, 0.0f);
+                            depth = 0;
+                            path_prim = -1;
+                            has_ray = true;
+                        } else { // defocus-disk rejection (utility.h:100-109): next Philox block in the next run
+                            p.d = pc;
+                            cam_block++;
+                        }
+                    } else {
                         f3 att, no, nd;
                         scatter(m, sc.texs, p.d, sf.point, sf.normal, sf.front_face, r, att, no, nd);
                         p.attenuation = p.attenuation * att; // camera.h:82-83
                         p.o = no; p.d = nd;
                         depth++;
-                        go_on = true;
+                        has_ray = true;
                     }
                 }
-                if (go_on) {
-                    has_ray = true;
-                } else { // path over: renderer.h:31
-                    col = col + p.color;
-                    if (sample == ra.ids_sample) primary = path_prim;
-                    s_idx++;
-                    state = s_idx < ra.spp ? ST_NEW : ST_FETCH;
+#endif
+                if (has_ray) {
+                    cnt.ray();
+                    hit.t = FLT_MAX; hit.code = -1; hit.near_tie = false;
+                    trav_begin<MODE_CLOSEST>(sc, p.o, p.d, tmin, hit, 0, 0.0f, tv, stack, cnt);
+                    phase = P_HIT; // what the lane does once tv.cur is CRT_BVH_NONE again (at once if the root box is missed)
                 }
-            }
-            if (state == ST_FETCH) {
-                if (q != NO_PIXEL) store_pixel(ra, out, ids, q, pixel, col, primary);
-                for (;;) {
-                    q = atomicAdd(work, 1u);
-                    if (q >= ra.local_pixels) { q = NO_PIXEL; state = ST_DONE; break; }
-                    const uint32_t tile = (q >> 6) * ra.tile_ranks + ra.tile_rank, l = q & 63u;
-                    i = (tile % ra.tiles_x) * 8u + (l & 7u);
-                    j = (tile / ra.tiles_x) * 8u + (l >> 3);
-                    if (i < ra.width && j < ra.height) { // renderer.h:22
-                        pixel = j * ra.width + i;      // renderer.h:24
-                        s_idx = 0;
-                        col = mk3(0.0f, 0.0f, 0.0f);
-                        primary = -1;
-                        state = ST_NEW;
-                        break;
-                    }
-                    if (ra.flags & RA_COMPACT) { out[3 * (size_t)q + 0] = 0.0f; out[3 * (size_t)q + 1] = 0.0f; out[3 * (size_t)q + 2] = 0.0f; }
-                }
-            }
-            if (state == ST_NEW) {
-                camera_ray(cam, i, j, pixel, ra.sample_offset + s_idx, ra.key0, ra.key1, p.o, p.d);
-                p.attenuation = mk3(1.0f, 1.0f, 1.0f);
-                p.color = mk3(0.0f, 0.0f, 0.0f);
-                depth = 0;
-                path_prim = -1;
-                has_ray = true;
-            }
-            if (has_ray) {
-                cnt.ray();
-                hit.t = FLT_MAX; hit.code = -1; hit.near_tie = false;
-                trav_begin<MODE_CLOSEST>(sc, p.o, p.d, tmin, hit, 0, 0.0f, tv, stack, cnt);
-                state = walk_state(tv.cur);
             }
         } else {
-            // ---- phase B ----
-#if CRT_WALK_POLICY == 0
-            for (;;) { // while-while: node steps until every walking lane is at a leaf (or done), then the leaves
-                while (state == ST_INNER) {
-                    if constexpr (COUNT_WORK) { const unsigned long long m_ = __ballot(true); if (lane == (uint32_t)__builtin_ctzll(m_)) { wc[4]++; wc[5] += popc64(m_); } }
-                    trav_inner(sc, tv, stack, cnt);
-                    state = walk_state(tv.cur);
-                }
-                if constexpr (COUNT_WORK) { const int nl = popc64(__ballot(state == ST_LEAF)); if (lane == 0) { wc[6] += nl ? 1 : 0; wc[7] += nl; } }
-                if (state == ST_LEAF) {
-                    trav_leaf<MODE_CLOSEST>(sc, p.o, p.d, tmin, hit, 0, 0.0f, tv, stack, cnt);
-                    state = walk_state(tv.cur);
-                }
-                const int nr = popc64(__ballot(state == ST_NEW || state == ST_HIT || state == ST_FETCH));
-                const int nw = popc64(__ballot(state == ST_INNER || state == ST_LEAF));
-                if (nw == 0 || nr >= threshold) break;
-            }
-#else
-            for (;;) { // one node step or one leaf step, whichever group of lanes is larger
-                const int n_inner = popc64(__ballot(state == ST_INNER));
-                const int n_leaf = popc64(__ballot(state == ST_LEAF));
+            // ================================ phase B ================================
+            const int alive = nready + nwalk;
+            for (;;) {
+                const bool inner = is_inner(tv.cur), leaf = tv.cur < 0;
+                const int n_inner = popc64(__ballot(inner)), n_leaf = popc64(__ballot(leaf));
+                const int nw = n_inner + n_leaf;
+                if (nw == 0 || alive - nw >= threshold) break;
                 if (n_inner >= n_leaf) {
                     if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_inner; } }
-                    if (state == ST_INNER) {
-                        trav_inner(sc, tv, stack, cnt);
-                        state = walk_state(tv.cur);
-                    }
+                    if (inner) trav_inner(sc, tv, stack, cnt);
                 } else {
                     if constexpr (COUNT_WORK) { if (lane == 0) { wc[6]++; wc[7] += n_leaf; } }
-                    if (state == ST_LEAF) {
-                        trav_leaf<MODE_CLOSEST>(sc, p.o, p.d, tmin, hit, 0, 0.0f, tv, stack, cnt);
-                        state = walk_state(tv.cur);
-                    }
+                    if (leaf) trav_leaf<MODE_CLOSEST>(sc, p.o, p.d, tmin, hit, 0, 0.0f, tv, stack, cnt);
                 }
-                const int nr = popc64(__ballot(state == ST_NEW || state == ST_HIT || state == ST_FETCH));
-                const int nw = popc64(__ballot(state == ST_INNER || state == ST_LEAF));
-                if (nw == 0 || nr >= threshold) break;
             }
-#endif
         }
     }
 

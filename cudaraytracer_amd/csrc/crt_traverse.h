@@ -106,19 +106,26 @@ CRT_HD float fast_rcp(float x)
 
 CRT_HD bool is_inner(int ref) { return (unsigned)ref < (unsigned)CRT_BVH_NONE; }
 
-// Spheres (a short flat list: ground + light in the reference scenes, scene.h:164-165), then the root box.
+// Spheres: a short flat list (ground + light in the reference scenes, scene.h:164-165), tested before the BVH.
 // MODE_CLOSEST: s.t must start at tmax (FLT_MAX).  MODE_NEXT_RANK: only candidates with t <= t_hi and
-// rank > after_rank are considered, s.rank must start at INT_MAX.  Leaves tv.cur = CRT_BVH_NONE if no node needs visiting.
-template <int MODE, class Stack, class Counters>
-CRT_HD void trav_begin(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Trav &tv, Stack &stack, Counters &cnt)
+// rank > after_rank are considered, s.rank must start at INT_MAX.
+template <int MODE, class Counters>
+CRT_HD void trav_spheres(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Counters &cnt)
 {
-    tv.cur = CRT_BVH_NONE;
     for (uint32_t k = 0; k < sc.nspheres; k++) {
         const Sphere sp = sc.spheres[k];
         float t;
         cnt.sphere();
         if (sphere_t(mk3(sp.cx, sp.cy, sp.cz), sp.radius, o, d, tmin, t)) offer<MODE>(s, t, (int)(sc.ntris + k), sp.rank, after_rank, t_hi);
     }
+}
+
+// Root box of the triangle BVH against the current best t: sets up the slab registers.  Leaves
+// tv.cur = CRT_BVH_NONE if no node needs visiting.
+template <int MODE>
+CRT_HD void trav_root(const SceneView &sc, f3 o, f3 d, const Search &s, float t_hi, Trav &tv)
+{
+    tv.cur = CRT_BVH_NONE;
     if (sc.root_ref == CRT_BVH_NONE) return;
     // slab arithmetic for pruning: idir finite, origin re-based to the root box entry so that rounding stays
     // small against the box margin wherever the ray starts.
@@ -140,6 +147,13 @@ CRT_HD void trav_begin(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, i
     tv.ood = mk3(ob.x * idir.x, ob.y * idir.y, ob.z * idir.z);
     tv.hi = ((MODE == MODE_CLOSEST) ? s.t : t_hi) - tv.shift + CRT_TIE_WINDOW;
     tv.cur = sc.root_ref;
+}
+
+template <int MODE, class Stack, class Counters>
+CRT_HD void trav_begin(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Trav &tv, Stack &stack, Counters &cnt)
+{
+    trav_spheres<MODE>(sc, o, d, tmin, s, after_rank, t_hi, cnt);
+    trav_root<MODE>(sc, o, d, s, t_hi, tv);
     stack.reset();
 }
 
@@ -147,7 +161,7 @@ CRT_HD void trav_begin(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, i
 template <class Stack, class Counters>
 CRT_HD void trav_inner(const SceneView &sc, Trav &tv, Stack &stack, Counters &cnt)
 {
-    const q4 *n = sc.nodes + 4 * (size_t)tv.cur;
+    const q4 *n = sc.nodes + 4u * (uint32_t)tv.cur;
     const q4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
     cnt.node();
     const f3 idir = tv.idir, ood = tv.ood;
@@ -168,17 +182,14 @@ CRT_HD void trav_inner(const SceneView &sc, Trav &tv, Stack &stack, Counters &cn
                                       __builtin_fminf(__builtin_fmaxf(a1z, b1z), hi));
     const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
     const int r0 = f2i(n0.w), r1 = f2i(n1.w);
-    if (h0 && h1) {
-        const bool swap = tn1 < tn0;
-        stack.push(swap ? r0 : r1);
-        tv.cur = swap ? r1 : r0;
-    } else if (h0) {
-        tv.cur = r0;
-    } else if (h1) {
-        tv.cur = r1;
-    } else {
-        tv.cur = stack.pop();
-    }
+    // branch-light selection: near child next, far child pushed; one hit: that child; none: pop
+    const bool swap = tn1 < tn0;
+    const int near_ref = swap ? r1 : r0, far_ref = swap ? r0 : r1;
+    const bool both = h0 && h1;
+    if (both) stack.push(far_ref);
+    int next = both ? near_ref : (h0 ? r0 : r1);
+    if (!h0 && !h1) next = stack.pop();
+    tv.cur = next;
 }
 
 // One leaf: its 1..8 triangle slots.  Requires tv.cur < 0.
@@ -188,7 +199,7 @@ CRT_HD void trav_leaf(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, in
     const uint32_t bits = (uint32_t)~tv.cur;
     const uint32_t first = bits >> 3, count = (bits & 7u) + 1u;
     for (uint32_t k = 0; k < count; k++) {
-        const q4 *tp = sc.tris + 3 * (size_t)(first + k);
+        const q4 *tp = sc.tris + 3u * (first + k);
         const q4 ta = tp[0], tb = tp[1], tc = tp[2];
         float t;
         cnt.tri();
