@@ -144,7 +144,8 @@ struct crt_scene {
     int device = -1;
     std::vector<uint32_t> rank;
     FlatBvh bvh;
-    void *d_nodes = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_mats = nullptr, *d_texs = nullptr;
+    std::vector<Shade> shades; // materials joined with their textures (device record)
+    void *d_nodes = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_shades = nullptr;
     unsigned long long *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint32_t max_waves = 0; // persistent-grid size: compute units x wave slots
@@ -156,9 +157,9 @@ struct crt_scene {
     void release_device()
     {
         if (device >= 0) (void)hipSetDevice(device);
-        void *ptrs[] = { d_nodes, d_tris, d_spheres, d_mats, d_texs, d_counters, d_stage_rgb, d_stage_ids };
+        void *ptrs[] = { d_nodes, d_tris, d_spheres, d_shades, d_counters, d_stage_rgb, d_stage_ids };
         for (void *p : ptrs) if (p) (void)hipFree(p);
-        d_nodes = d_tris = d_spheres = d_mats = d_texs = nullptr; d_counters = nullptr; d_stage_rgb = nullptr; d_stage_ids = nullptr;
+        d_nodes = d_tris = d_spheres = d_shades = nullptr; d_counters = nullptr; d_stage_rgb = nullptr; d_stage_ids = nullptr;
         stage_rgb_floats = stage_ids = 0;
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -289,6 +290,22 @@ extern "C" int crt_scene_commit(crt_scene *s, int device)
         o.id = (int)(s->tris.size() + k); o.rank = (int)s->rank[s->tris.size() + k]; o.mat = s->spheres[k].material; o.pad = 0;
     }
 
+    s->shades.assign(s->mats.size(), Shade{});
+    for (size_t k = 0; k < s->mats.size(); k++) {
+        const Material &m = s->mats[k];
+        Shade &o = s->shades[k];
+        o.type = m.type; o.param = m.param; o.tex_type = TEX_SOLID;
+        if (m.type == MAT_LAMBERTIAN || m.type == MAT_DIFFUSE_LIGHT) { // the materials that own a texture (material.h:22,107)
+            const Texture &t = s->texs[(size_t)m.tex];
+            o.tex_type = t.type; o.inv_scale = t.inv_scale;
+            o.ar = t.ar; o.ag = t.ag; o.ab = t.ab; o.br = t.br; o.bg = t.bg; o.bb = t.bb;
+        } else if (m.type == MAT_METAL) { // material.h:48
+            o.ar = m.r; o.ag = m.g; o.ab = m.b;
+        } else { // Dielectric, material.h:66
+            o.ar = o.ag = o.ab = 1.0f;
+        }
+    }
+
     s->prepared = true;
     if (device == CRT_DEVICE_NONE) return CRT_OK; // host-side preparation only (ranks, BVH); rendering stays unavailable
 
@@ -301,8 +318,7 @@ extern "C" int crt_scene_commit(crt_scene *s, int device)
     if ((rc = upload(&s->d_nodes, s->bvh.nodes))) return rc;
     if ((rc = upload(&s->d_tris, s->bvh.tris))) return rc;
     if ((rc = upload(&s->d_spheres, spheres))) return rc;
-    if ((rc = upload(&s->d_mats, s->mats))) return rc;
-    if ((rc = upload(&s->d_texs, s->texs))) return rc;
+    if ((rc = upload(&s->d_shades, s->shades))) return rc;
     HIP_TRY(hipMalloc((void **)&s->d_counters, 24 * sizeof(unsigned long long)));
     {
         hipDeviceProp_t prop;
@@ -314,7 +330,7 @@ extern "C" int crt_scene_commit(crt_scene *s, int device)
 
     SceneView &v = s->view;
     v.nodes = (const q4 *)s->d_nodes; v.tris = (const q4 *)s->d_tris; v.spheres = (const Sphere *)s->d_spheres;
-    v.mats = (const Material *)s->d_mats; v.texs = (const Texture *)s->d_texs;
+    v.shades = (const Shade *)s->d_shades;
     v.root_ref = s->bvh.root_ref; v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size();
     v.root_min = s->bvh.root_box.mn; v.root_max = s->bvh.root_box.mx;
     s->committed = true;

@@ -177,6 +177,14 @@ CRT_HD bool sphere_accepts(float t, float closest) { return t <= closest; }
 struct Material { int type; float r, g, b; float param; int tex; int pad0, pad1; };               // 32 B
 struct Texture { int type; float ar, ag, ab; float br, bg, bb; float inv_scale; };                // 32 B
 struct Sphere { float cx, cy, cz, radius; int id; int rank; int mat; int pad; };                  // 32 B
+// Device record of a material joined with its texture (48 B, built at commit): one fetch per shaded hit instead
+// of material -> texture.  Colour a/b: the texture of a Lambertian / DiffuseLight (texture.h), the albedo of a Metal
+// (material.h:48) and (1,1,1) for a Dielectric (material.h:66), so that every material's colour is texture_value().
+struct alignas(16) Shade {
+    int type; float param; int tex_type; float inv_scale;
+    float ar, ag, ab, pad1; // solid colour / odd checker cells
+    float br, bg, bb, pad2; // even checker cells
+};
 
 enum { MAT_LAMBERTIAN = 0, MAT_METAL = 1, MAT_DIFFUSE_LIGHT = 2, MAT_DIELECTRIC = 3 };
 enum { TEX_SOLID = 0, TEX_CHECKER = 1 };
@@ -188,10 +196,10 @@ struct CameraPOD { // mirrors crt_camera (include/crt.h)
 };
 
 // texture.h:16, 31-39.  `a` is returned where the floor-sum is odd (the reference's `is_even` is true then).
-CRT_HD f3 texture_value(const Texture &t, f3 p)
+CRT_HD f3 texture_value(const Shade &t, f3 p)
 {
     const f3 ca = mk3(t.ar, t.ag, t.ab);
-    if (t.type == TEX_SOLID) return ca;
+    if (t.tex_type == TEX_SOLID) return ca;
     const int xi = (int)__builtin_floorf(t.inv_scale * p.x);
     const int yi = (int)__builtin_floorf(t.inv_scale * p.y);
     const int zi = (int)__builtin_floorf(t.inv_scale * p.z);
@@ -226,27 +234,25 @@ CRT_HD float reflectance(float cosine, float ri)
 
 // material.h scatter().  rnd = first Philox block of stage 1+depth (x, y = theta, phi uniforms; the dielectric
 // uses x).  Returns false when the path ends (base Material / DiffuseLight, material.h:14-16).
-CRT_HD bool scatter(const Material &m, const Texture *texs, f3 ray_d, f3 point, f3 normal, bool front_face, u4 rnd,
+// `colour` = texture_value() of the material's Shade record at the hit point.
+CRT_HD bool scatter(int type, float param, f3 colour, f3 ray_d, f3 point, f3 normal, bool front_face, u4 rnd,
                     f3 &attenuation, f3 &new_o, f3 &new_d)
 {
-    if (m.type == MAT_LAMBERTIAN || m.type == MAT_METAL) {
+    f3 no = point, nd = ray_d; // locals, written out once (keeps the outputs in registers)
+    bool ok = false;
+    if (type == MAT_LAMBERTIAN || type == MAT_METAL) {
         const f3 ruv = random_unit_vector(u01(rnd.x), u01(rnd.y)); // shared by both: the wave evaluates it once
-        if (m.type == MAT_LAMBERTIAN) { // material.h:24-34
+        if (type == MAT_LAMBERTIAN) { // material.h:24-34
             f3 dir = normal + ruv;
             if (length(dir) <= 1e-8f) dir = normal;
-            new_d = dir;
-            attenuation = texture_value(texs[m.tex], point);
+            nd = dir;
         } else { // material.h:44-51 (always scatters)
             const f3 reflected = reflect(ray_d, normal);
-            new_d = axpy(m.param, ruv, normalize(reflected));
-            attenuation = mk3(m.r, m.g, m.b);
+            nd = axpy(param, ruv, normalize(reflected));
         }
-        new_o = point;
-        return true;
-    }
-    if (m.type == MAT_DIELECTRIC) { // material.h:61-91
-        attenuation = mk3(1.0f, 1.0f, 1.0f);
-        const float ri = front_face ? 1.0f / m.param : m.param;
+        ok = true;
+    } else if (type == MAT_DIELECTRIC) { // material.h:61-91
+        const float ri = front_face ? 1.0f / param : param;
         const f3 unit_direction = normalize(ray_d);
         const float cos_theta = __builtin_fminf(dot(-unit_direction, normal), 1.0f);
         const float sin_theta = __builtin_sqrtf(fma1(-cos_theta, cos_theta, 1.0f));
@@ -254,19 +260,17 @@ CRT_HD bool scatter(const Material &m, const Texture *texs, f3 ray_d, f3 point, 
         f3 direction;
         if (is_reflect || reflectance(cos_theta, ri) > fma1(u01(rnd.x), 1.0f - 0.0f, 0.0f)) direction = reflect(unit_direction, normal);
         else direction = refract(unit_direction, normal, ri);
-        new_o = axpy(1e-3f, direction, point);
-        new_d = direction;
-        return true;
+        no = axpy(1e-3f, direction, point);
+        nd = direction;
+        ok = true;
     }
-    return false;
+    attenuation = colour;
+    new_o = no; new_d = nd;
+    return ok;
 }
-CRT_HD bool scatters(const Material &m) { return m.type == MAT_LAMBERTIAN || m.type == MAT_METAL || m.type == MAT_DIELECTRIC; }
+CRT_HD bool scatters(int type) { return type == MAT_LAMBERTIAN || type == MAT_METAL || type == MAT_DIELECTRIC; }
 // material.h:10-12, 109-111
-CRT_HD f3 emitted(const Material &m, const Texture *texs, f3 point)
-{
-    if (m.type == MAT_DIFFUSE_LIGHT) return texture_value(texs[m.tex], point);
-    return mk3(0.0f, 0.0f, 0.0f);
-}
+CRT_HD f3 emitted(int type, f3 colour) { return type == MAT_DIFFUSE_LIGHT ? colour : mk3(0.0f, 0.0f, 0.0f); }
 
 // camera.h:88-98 get_ray + 111-119.  Philox stage 0: block 0 = (square.x, square.y, disk0.x, disk0.y), block k>=1
 // = disk draws 2k-1 and 2k; utility.h:100-109 makes up to 10 rejection rounds and returns the 11th unconditionally.

@@ -11,10 +11,6 @@
 
 namespace crt {
 
-#ifndef CRT_EXP_TWO_PHILOX
-#define CRT_EXP_TWO_PHILOX 1
-#endif
-
 // Per-lane traversal stack: an LDS column (stack[level][lane]: bank = lane, conflict free).  Level 0 holds the
 // CRT_BVH_NONE sentinel for the whole kernel, so pop() needs no empty check: popping it ends the walk.
 struct LdsStack {
@@ -93,9 +89,17 @@ enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
 //      larger, until enough lanes wait for phase A again.
 // A lane's own operation sequence is exactly the sequential one (crt_traverse.h: sample_radiance), so results do not
 // depend on the schedule.  (Two pixel contexts per lane were tried and measured slower: DESIGN.md section 7.)
+#ifndef CRT_WAVES_PER_EU
+#define CRT_WAVES_PER_EU 5 // 512 VGPRs / 5 waves -> 96 registers per lane; the few spills this forces sit on the rare tie path
+#endif
+#if CRT_WAVES_PER_EU > 0
+#define CRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(CRT_WAVES_PER_EU, CRT_WAVES_PER_EU)))
+#else
+#define CRT_OCCUPANCY_ATTR
+#endif
 template <bool COUNT_WORK>
-__global__ __launch_bounds__(64) void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
-                                                    int *__restrict__ ids, unsigned long long *__restrict__ counters)
+__global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
+                                                                       int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
     __shared__ int lds_stack[(CRT_STACK_DEPTH + 1) * 64];
     const uint32_t lane = threadIdx.x;
@@ -112,17 +116,16 @@ __global__ __launch_bounds__(64) void render_kernel(SceneView sc, CameraPOD cam,
     int primary = -1, path_prim = -1;
     int phase = P_FETCH;
     uint32_t s_idx = 0, depth = 0;
-#if !CRT_EXP_TWO_PHILOX
-    uint32_t cam_block = 0;
-#endif
     Path p;
     p.o = p.d = p.attenuation = p.color = mk3(0.0f, 0.0f, 0.0f);
     Search hit;
-    hit.t = FLT_MAX; hit.code = -1; hit.rank = 0; hit.near_tie = false;
+    hit.t = FLT_MAX; hit.code = -1; hit.mat = 0; hit.rank = 0; hit.near_tie = false;
     Trav tv;
     tv.idir = tv.ood = mk3(0.0f, 0.0f, 0.0f); tv.shift = 0.0f; tv.hi = 0.0f; tv.cur = CRT_BVH_NONE;
     const int threshold = (int)ra.sched_threshold;
     uint32_t wc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // schedule counters, lane 0 only (COUNT_WORK)
+    unsigned long long t_start = 0;
+    if constexpr (COUNT_WORK) t_start = wall_clock64(); // 100 MHz
 
     for (;;) {
         const bool walking = tv.cur != CRT_BVH_NONE;
@@ -135,37 +138,41 @@ __global__ __launch_bounds__(64) void render_kernel(SceneView sc, CameraPOD cam,
             if (!walking && phase != P_DONE) {
                 bool want_scatter = false;
                 Surface sf;
-                sf.point = sf.normal = mk3(0.0f, 0.0f, 0.0f); sf.front_face = false; sf.material = 0; sf.prim = -1;
-                Material m;
-                m.type = MAT_DIFFUSE_LIGHT; m.r = m.g = m.b = m.param = 0.0f; m.tex = 0; m.pad0 = m.pad1 = 0;
+                sf.point = sf.normal = mk3(0.0f, 0.0f, 0.0f); sf.front_face = false; sf.prim = -1;
+                int m_type = MAT_DIFFUSE_LIGHT;
+                float m_param = 0.0f;
+                f3 colour = mk3(0.0f, 0.0f, 0.0f);
                 if (phase == P_HIT) {
                     float t = 0.0f;
-                    const int code = resolve_hit(sc, p.o, p.d, tmin, FLT_MAX, hit, t, stack, cnt);
+                    int mat = 0;
+                    const int code = resolve_hit(sc, p.o, p.d, tmin, FLT_MAX, hit, t, mat, stack, cnt);
                     if (code < 0) { // camera.h:68-71
                         p.color = mk3(fma1(p.attenuation.x, cam.background.x, p.color.x), fma1(p.attenuation.y, cam.background.y, p.color.y),
                                       fma1(p.attenuation.z, cam.background.z, p.color.z));
                     } else {
+                        const Shade m = sc.shades[mat]; // issued together with the primitive fetch below: one memory round trip per hit
                         sf = surface_at(sc, code, p.o, p.d, t);
                         cnt.shade();
                         if (depth == 0) path_prim = sf.prim;
-                        m = sc.mats[sf.material];
-                        const f3 e = emitted(m, sc.texs, sf.point); // camera.h:73-74
+                        m_type = m.type; m_param = m.param;
+                        colour = texture_value(m, sf.point);
+                        const f3 e = emitted(m_type, colour); // camera.h:73-74
                         p.color = mk3(fma1(p.attenuation.x, e.x, p.color.x), fma1(p.attenuation.y, e.y, p.color.y), fma1(p.attenuation.z, e.z, p.color.z));
                         // camera.h:66,78: the scatter of the last allowed bounce cannot reach the image: not evaluated
-                        want_scatter = scatters(m) && depth + 1 < ra.max_depth;
+                        want_scatter = scatters(m_type) && depth + 1 < ra.max_depth;
                     }
                     if (!want_scatter) { // path over: renderer.h:31
                         col = col + p.color;
                         if (ra.sample_offset + s_idx == ra.ids_sample) primary = path_prim;
                         s_idx++;
-#if !CRT_EXP_TWO_PHILOX
-                        cam_block = 0;
-#endif
                         phase = s_idx < ra.spp ? P_NEW : P_FETCH;
                     }
                 }
                 if (phase == P_FETCH) {
                     if (q != NO_PIXEL) store_pixel(ra, out, ids, q, pixel, col, primary);
+                    // Raster tile order on purpose.  Measured slower: fetching one pixel ahead (+15 %: a lane then holds a
+                    // pixel hostage at the end of the frame), the tiles over the mesh first (+14 %), spread evenly (+5 %),
+                    // or started at the mesh's first tile row (+11 %): DESIGN.md section 7.
                     for (;;) {
                         q = atomicAdd(work, 1u);
                         if (q >= ra.local_pixels) { q = NO_PIXEL; phase = P_DONE; break; }
@@ -175,9 +182,6 @@ __global__ __launch_bounds__(64) void render_kernel(SceneView sc, CameraPOD cam,
                         if (i < ra.width && j < ra.height) { // renderer.h:22
                             pixel = j * ra.width + i;      // renderer.h:24
                             s_idx = 0;
-#if !CRT_EXP_TWO_PHILOX
-                            cam_block = 0;
-#endif
                             col = mk3(0.0f, 0.0f, 0.0f);
                             primary = -1;
                             phase = P_NEW;
@@ -187,11 +191,10 @@ __global__ __launch_bounds__(64) void render_kernel(SceneView sc, CameraPOD cam,
                     }
                 }
                 bool has_ray = false;
-#if CRT_EXP_TWO_PHILOX
                 if (want_scatter) {
                     const u4 r = philox4x32_10(pixel, ra.sample_offset + s_idx, 1u + depth, 0u, ra.key0, ra.key1);
                     f3 att, no, nd;
-                    scatter(m, sc.texs, p.d, sf.point, sf.normal, sf.front_face, r, att, no, nd);
+                    scatter(m_type, m_param, colour, p.d, sf.point, sf.normal, sf.front_face, r, att, no, nd);
                     p.attenuation = p.attenuation * att; // camera.h:82-83
                     p.o = no; p.d = nd;
                     depth++;
@@ -205,32 +208,6 @@ __global__ __launch_bounds__(64) void render_kernel(SceneView sc, CameraPOD cam,
                     path_prim = -1;
                     has_ray = true;
                 }
-#else
-                if (want_scatter || phase == P_NEW) {
-                    const bool is_cam = !want_scatter;
-                    const u4 r = philox4x32_10(pixel, ra.sample_offset + s_idx, is_cam ? 0u : 1u + depth, is_cam ? cam_block : 0u, ra.key0, ra.key1);
-                    if (is_cam) {
-                        f3 pc = p.d; // between defocus-disk retries the pixel point is parked in p.d
-                        if (camera_ray_step(cam, i, j, cam_block, r, pc, p.o, p.d)) {
-                            p.attenuation = mk3(1.0f, 1.0f, 1.0f);
-                            p.color = mk3(0.0f, 0.0f, 0.0f);
-                            depth = 0;
-                            path_prim = -1;
-                            has_ray = true;
-                        } else { // defocus-disk rejection (utility.h:100-109): next Philox block in the next run
-                            p.d = pc;
-                            cam_block++;
-                        }
-                    } else {
-                        f3 att, no, nd;
-                        scatter(m, sc.texs, p.d, sf.point, sf.normal, sf.front_face, r, att, no, nd);
-                        p.attenuation = p.attenuation * att; // camera.h:82-83
-                        p.o = no; p.d = nd;
-                        depth++;
-                        has_ray = true;
-                    }
-                }
-#endif
                 if (has_ray) {
                     cnt.ray();
                     hit.t = FLT_MAX; hit.code = -1; hit.near_tie = false;
@@ -271,9 +248,16 @@ __global__ __launch_bounds__(64) void render_kernel(SceneView sc, CameraPOD cam,
             atomicAdd(&counters[3], (unsigned long long)sp);
         }
 #pragma unroll
-        for (int k = 0; k < 10; k++) {
+        for (int k = 0; k < 8; k++) {
             const uint32_t w = wave_sum(wc[k]);
             if (lane == 0) atomicAdd(&counters[8 + k], (unsigned long long)w);
+        }
+        // load balance: waves that did work, the sum and the maximum of their lifetimes (10 ns ticks)
+        if (lane == 0 && wc[0] > 1) {
+            const unsigned long long dt = wall_clock64() - t_start;
+            atomicAdd(&counters[16], 1ull);
+            atomicAdd(&counters[17], dt);
+            atomicMax(&counters[10], dt);
         }
     }
 }

@@ -44,8 +44,7 @@ struct SceneView {
     const q4 *nodes;
     const q4 *tris;
     const Sphere *spheres;
-    const Material *mats;
-    const Texture *texs;
+    const Shade *shades; // per material id
     int root_ref;        // BVH_NONE when there are no triangles
     uint32_t ntris;      // triangle slots
     uint32_t nspheres;
@@ -71,18 +70,19 @@ enum { MODE_CLOSEST = 0, MODE_NEXT_RANK = 1 };
 struct Search {
     float t;       // MODE_CLOSEST: smallest t so far.  MODE_NEXT_RANK: t of the candidate found
     int code;
+    int mat;       // material id of `code` (carried so that the shading record is fetched without waiting for the primitive)
     int rank;      // MODE_NEXT_RANK: rank of the candidate found (smallest rank > after_rank)
     bool near_tie; // MODE_CLOSEST: two candidates within CRT_TIE_WINDOW of each other were seen
 };
 
 template <int MODE>
-CRT_HD void offer(Search &s, float t, int code, int rank, int after_rank, float t_hi)
+CRT_HD void offer(Search &s, float t, int code, int mat, int rank, int after_rank, float t_hi)
 {
     if (MODE == MODE_CLOSEST) {
         if (s.code >= 0 && __builtin_fabsf(t - s.t) <= CRT_TIE_WINDOW) s.near_tie = true;
-        if (t < s.t) { s.t = t; s.code = code; }
+        if (t < s.t) { s.t = t; s.code = code; s.mat = mat; }
     } else {
-        if (t <= t_hi && rank > after_rank && rank < s.rank) { s.t = t; s.code = code; s.rank = rank; }
+        if (t <= t_hi && rank > after_rank && rank < s.rank) { s.t = t; s.code = code; s.mat = mat; s.rank = rank; }
     }
 }
 
@@ -116,7 +116,7 @@ CRT_HD void trav_spheres(const SceneView &sc, f3 o, f3 d, float tmin, Search &s,
         const Sphere sp = sc.spheres[k];
         float t;
         cnt.sphere();
-        if (sphere_t(mk3(sp.cx, sp.cy, sp.cz), sp.radius, o, d, tmin, t)) offer<MODE>(s, t, (int)(sc.ntris + k), sp.rank, after_rank, t_hi);
+        if (sphere_t(mk3(sp.cx, sp.cy, sp.cz), sp.radius, o, d, tmin, t)) offer<MODE>(s, t, (int)(sc.ntris + k), sp.mat, sp.rank, after_rank, t_hi);
     }
 }
 
@@ -204,7 +204,7 @@ CRT_HD void trav_leaf(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, in
         float t;
         cnt.tri();
         if (triangle_t(mk3(ta.x, ta.y, ta.z), mk3(tb.x, tb.y, tb.z), mk3(tc.x, tc.y, tc.z), o, d, tmin, t)) {
-            offer<MODE>(s, t, (int)(first + k), f2i(tb.w), after_rank, t_hi);
+            offer<MODE>(s, t, (int)(first + k), f2i(tc.w), f2i(tb.w), after_rank, t_hi);
             if (MODE == MODE_CLOSEST) tv.hi = s.t - tv.shift + CRT_TIE_WINDOW;
         }
     }
@@ -226,22 +226,22 @@ CRT_HD void walk(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int aft
 // After a MODE_CLOSEST walk: the reference's winner.  Fast path when no two candidates came within the tie
 // window; otherwise the fold in reference leaf order (one MODE_NEXT_RANK walk per candidate in the window).
 template <class Stack, class Counters>
-CRT_HD int resolve_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, const Search &s, float &t_hit, Stack &stack, Counters &cnt)
+CRT_HD int resolve_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, const Search &s, float &t_hit, int &mat_hit, Stack &stack, Counters &cnt)
 {
     if (s.code < 0) return -1;
     // sphere.h:36 / triangle.h:75 also bound t by the caller's tmax (FLT_MAX everywhere in the reference)
-    if (!s.near_tie) { t_hit = s.t; return s.t <= tmax ? s.code : -1; }
+    if (!s.near_tie) { t_hit = s.t; mat_hit = s.mat; return s.t <= tmax ? s.code : -1; }
     cnt.refold();
     const float t_hi = s.t + CRT_TIE_WINDOW;
     float closest = tmax;
     int win = -1, after = -1;
     for (;;) {
         Search n;
-        n.t = 0.0f; n.code = -1; n.rank = 0x7FFFFFFF; n.near_tie = false;
+        n.t = 0.0f; n.code = -1; n.mat = 0; n.rank = 0x7FFFFFFF; n.near_tie = false;
         walk<MODE_NEXT_RANK>(sc, o, d, tmin, n, after, t_hi, stack, cnt);
         if (n.code < 0) break;
         const bool is_tri = (uint32_t)n.code < sc.ntris;
-        if (is_tri ? triangle_accepts(n.t, closest) : sphere_accepts(n.t, closest)) { closest = n.t; win = n.code; }
+        if (is_tri ? triangle_accepts(n.t, closest) : sphere_accepts(n.t, closest)) { closest = n.t; win = n.code; mat_hit = n.mat; }
         after = n.rank;
     }
     t_hit = closest;
@@ -251,18 +251,18 @@ CRT_HD int resolve_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, 
 // world->hit(ray, Interval(tmin, FLT_MAX), rec) (camera.h:68 -> hittable_list.h:17-63): returns the winning
 // primitive code (-1 = miss) and its t.
 template <class Stack, class Counters>
-CRT_HD int closest_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float &t_hit, Stack &stack, Counters &cnt)
+CRT_HD int closest_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float &t_hit, int &mat_hit, Stack &stack, Counters &cnt)
 {
     cnt.ray();
     Search s;
-    s.t = tmax; s.code = -1; s.rank = 0; s.near_tie = false;
+    s.t = tmax; s.code = -1; s.mat = 0; s.rank = 0; s.near_tie = false;
     walk<MODE_CLOSEST>(sc, o, d, tmin, s, 0, 0.0f, stack, cnt);
-    return resolve_hit(sc, o, d, tmin, tmax, s, t_hit, stack, cnt);
+    return resolve_hit(sc, o, d, tmin, tmax, s, t_hit, mat_hit, stack, cnt);
 }
 
-// Hit record of the winning primitive: point, face-forward normal, material, primitive id
+// Hit record of the winning primitive: point, face-forward normal, primitive id (its material id travels with the search)
 // (triangle.h:78-83, sphere.h:43-47, hittable.h:18-21).
-struct Surface { f3 point, normal; bool front_face; int material; int prim; };
+struct Surface { f3 point, normal; bool front_face; int prim; };
 
 CRT_HD Surface surface_at(const SceneView &sc, int code, f3 o, f3 d, float t)
 {
@@ -274,13 +274,11 @@ CRT_HD Surface surface_at(const SceneView &sc, int code, f3 o, f3 d, float t)
         const f3 a = mk3(ta.x, ta.y, ta.z);
         const f3 n = normalize(cross(mk3(tb.x, tb.y, tb.z) - a, mk3(tc.x, tc.y, tc.z) - a));
         r.normal = face_normal(d, n, r.front_face);
-        r.material = f2i(tc.w);
         r.prim = f2i(ta.w);
     } else {
         const Sphere sp = sc.spheres[(uint32_t)code - sc.ntris];
         const f3 outward = div3(r.point - mk3(sp.cx, sp.cy, sp.cz), sp.radius);
         r.normal = face_normal(d, outward, r.front_face);
-        r.material = sp.mat;
         r.prim = sp.id;
     }
     return r;
@@ -291,7 +289,7 @@ CRT_HD Surface surface_at(const SceneView &sc, int code, f3 o, f3 d, float t)
 struct Path { f3 o, d, attenuation, color; };
 
 template <class Counters>
-CRT_HD bool path_bounce(const SceneView &sc, const CameraPOD &cam, Path &p, int code, float t, uint32_t depth, uint32_t pixel, uint32_t sample,
+CRT_HD bool path_bounce(const SceneView &sc, const CameraPOD &cam, Path &p, int code, float t, int mat, uint32_t depth, uint32_t pixel, uint32_t sample,
                         uint32_t k0, uint32_t k1, Counters &cnt, int &primary_prim)
 {
     if (code < 0) {
@@ -299,16 +297,17 @@ CRT_HD bool path_bounce(const SceneView &sc, const CameraPOD &cam, Path &p, int 
                       fma1(p.attenuation.z, cam.background.z, p.color.z));
         return false;
     }
+    const Shade m = sc.shades[mat];
     const Surface sf = surface_at(sc, code, p.o, p.d, t);
     cnt.shade();
     if (depth == 0) primary_prim = sf.prim;
-    const Material m = sc.mats[sf.material];
-    const f3 e = emitted(m, sc.texs, sf.point);
+    const f3 colour = texture_value(m, sf.point);
+    const f3 e = emitted(m.type, colour);
     p.color = mk3(fma1(p.attenuation.x, e.x, p.color.x), fma1(p.attenuation.y, e.y, p.color.y), fma1(p.attenuation.z, e.z, p.color.z));
-    if (!scatters(m)) return false; // material.h:14-16
+    if (!scatters(m.type)) return false; // material.h:14-16
     const u4 rnd = philox4x32_10(pixel, sample, 1u + depth, 0u, k0, k1);
     f3 att, no, nd;
-    if (!scatter(m, sc.texs, p.d, sf.point, sf.normal, sf.front_face, rnd, att, no, nd)) return false;
+    if (!scatter(m.type, m.param, colour, p.d, sf.point, sf.normal, sf.front_face, rnd, att, no, nd)) return false;
     p.attenuation = p.attenuation * att;
     p.o = no; p.d = nd;
     return true;
@@ -327,8 +326,9 @@ CRT_HD f3 sample_radiance(const SceneView &sc, const CameraPOD &cam, uint32_t i,
     primary_prim = -1;
     for (uint32_t depth = 0; depth < max_depth; depth++) {
         float t = 0.0f;
-        const int code = closest_hit(sc, p.o, p.d, 0.001f, FLT_MAX, t, stack, cnt);
-        if (!path_bounce(sc, cam, p, code, t, depth, pixel, sample, k0, k1, cnt, primary_prim)) break;
+        int mat = 0;
+        const int code = closest_hit(sc, p.o, p.d, 0.001f, FLT_MAX, t, mat, stack, cnt);
+        if (!path_bounce(sc, cam, p, code, t, mat, depth, pixel, sample, k0, k1, cnt, primary_prim)) break;
     }
     return p.color;
 }

@@ -127,8 +127,9 @@ typedef struct crt_stats {
     uint64_t sphere_tests;  /* 32-byte sphere records tested    (CRT_COUNT_WORK)                            */
     uint64_t tie_refolds;   /* rays that took the exact reference-order tie fold                            */
     uint64_t shaded_hits;   /* rays that hit something and were shaded (CRT_COUNT_WORK)                     */
-    uint64_t sched[10];     /* schedule counters (CRT_COUNT_WORK): for each lane state NEW, BEGIN, INNER, LEAF, HIT the
-                               number of wave steps run for it and the lanes that took part                          */
+    uint64_t sched[10];     /* schedule counters (CRT_COUNT_WORK): [0] shade-phase runs [1] lanes in them [2] longest wave
+                               lifetime, 10 ns ticks [4] node steps [5] lanes in them [6] leaf steps [7] lanes in them
+                               [8] waves that rendered pixels [9] sum of their lifetimes, 10 ns ticks               */
     float kernel_ms;        /* hipEvent time of the render kernel on `stream`                               */
     uint32_t reserved;
 } crt_stats;

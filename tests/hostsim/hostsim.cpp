@@ -41,7 +41,7 @@ SceneView host_view(const crt_scene *s, std::vector<Sphere> &spheres)
         o.id = (int)(s->tris.size() + k); o.rank = (int)s->rank[s->tris.size() + k]; o.mat = s->spheres[k].material; o.pad = 0;
     }
     SceneView v{};
-    v.nodes = s->bvh.nodes.data(); v.tris = s->bvh.tris.data(); v.spheres = spheres.data(); v.mats = s->mats.data(); v.texs = s->texs.data();
+    v.nodes = s->bvh.nodes.data(); v.tris = s->bvh.tris.data(); v.spheres = spheres.data(); v.shades = s->shades.data();
     v.root_ref = s->bvh.root_ref; v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size();
     v.root_min = s->bvh.root_box.mn; v.root_max = s->bvh.root_box.mx;
     return v;
@@ -100,11 +100,11 @@ extern "C" int hostsim_trace(const crt_scene *s, const float o_[3], const float 
     ArrayStack stack;
     const f3 o = mk3(o_[0], o_[1], o_[2]), d = mk3(d_[0], d_[1], d_[2]);
     float t = 0.0f;
-    int code;
+    int code, mat = 0;
     if (!force_tie_path) {
-        code = closest_hit(sc, o, d, tmin, FLT_MAX, t, stack, cnt);
+        code = closest_hit(sc, o, d, tmin, FLT_MAX, t, mat, stack, cnt);
     } else {
-        Search q; q.t = FLT_MAX; q.code = -1; q.rank = 0; q.near_tie = false;
+        Search q; q.t = FLT_MAX; q.code = -1; q.mat = 0; q.rank = 0; q.near_tie = false;
         walk<MODE_CLOSEST>(sc, o, d, tmin, q, 0, 0.0f, stack, cnt);
         code = -1;
         if (q.code >= 0) {
@@ -113,7 +113,7 @@ extern "C" int hostsim_trace(const crt_scene *s, const float o_[3], const float 
             float closest = FLT_MAX;
             int after = -1;
             for (;;) {
-                Search n; n.t = 0.0f; n.code = -1; n.rank = 0x7FFFFFFF; n.near_tie = false;
+                Search n; n.t = 0.0f; n.code = -1; n.mat = 0; n.rank = 0x7FFFFFFF; n.near_tie = false;
                 walk<MODE_NEXT_RANK>(sc, o, d, tmin, n, after, t_hi, stack, cnt);
                 if (n.code < 0) break;
                 const bool is_tri = (uint32_t)n.code < sc.ntris;
