@@ -331,7 +331,7 @@ extern "C" int crt_scene_commit(crt_scene *s, int device)
     SceneView &v = s->view;
     v.nodes = (const q4 *)s->d_nodes; v.tris = (const q4 *)s->d_tris; v.spheres = (const Sphere *)s->d_spheres;
     v.shades = (const Shade *)s->d_shades;
-    v.root_ref = s->bvh.root_ref; v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size();
+    v.root_ref = s->bvh.root_ref; v.nnodes = (uint32_t)(s->bvh.nodes.size() / 4); v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size();
     v.root_min = s->bvh.root_box.mn; v.root_max = s->bvh.root_box.mx;
     s->committed = true;
     return CRT_OK;
@@ -441,7 +441,10 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
     ra.tile_rank = p->tile_rank; ra.tile_ranks = p->tile_ranks;
     ra.flags = ((p->flags & CRT_OUT_ACCUM) ? (uint32_t)RA_ACCUM : 0u) | ((p->flags & CRT_OUT_COMPACT) ? (uint32_t)RA_COMPACT : 0u);
     ra.key0 = (uint32_t)p->seed; ra.key1 = (uint32_t)(p->seed >> 32);
-    ra.sched_threshold = (uint32_t)std::min(std::max(get_env_int("CRT_SCHED_THRESHOLD", 40), 1), 64);
+    ra.kernel = get_env_int("CRT_KERNEL", 0) == 1 ? (uint32_t)RK_POOL : (uint32_t)RK_LANES;
+    ra.sched_threshold = ra.kernel == RK_POOL ? (uint32_t)std::min(std::max(get_env_int("CRT_POOL_REFILL", 16), 1), 63)
+                                              : (uint32_t)std::min(std::max(get_env_int("CRT_SCHED_THRESHOLD", 40), 1), 64);
+    ra.bvh_depth = s->bvh.depth;
 
     const size_t npix = (size_t)p->width * p->height;
     const size_t rgb_floats = (p->flags & CRT_OUT_COMPACT) ? (size_t)crt_compact_floats(p->width, p->height, p->tile_ranks) : npix * 3;

@@ -10,6 +10,7 @@
 namespace crt {
 
 enum { RA_ACCUM = 1u, RA_COMPACT = 2u };
+enum { RK_LANES = 0u, RK_POOL = 1u }; // render_kernel (pixel per lane) / render_pool_kernel (context pool in LDS)
 
 struct RenderArgs {
     uint32_t width, height, tiles_x, tiles_y;
@@ -17,7 +18,10 @@ struct RenderArgs {
     uint32_t tile_rank, tile_ranks, flags;
     uint32_t key0, key1;
     uint32_t local_pixels;    // 64 * (tiles of this rank): pixel slots handed out by the device-wide counter (set by launch_render)
-    uint32_t sched_threshold; // lanes that must wait for the shade/regenerate phase before it runs (1..64)
+    uint32_t sched_threshold; // RK_LANES: lanes that must wait for the shade/regenerate phase before it runs (1..64)
+                              // RK_POOL: free lanes that end a run of walk steps (1..63)
+    uint32_t kernel;          // RK_*
+    uint32_t bvh_depth;       // levels of the triangle BVH (selects the LDS stack size)
 };
 
 // counters: 24 x uint64 ([8..17] = wave-level schedule counters, crt_stats.sched) on the device: [0] rays [1] nodes [2] triangle tests [3] sphere tests [4] tie refolds [5] shaded hits [6] pixel work counter

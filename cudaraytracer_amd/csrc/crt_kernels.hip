@@ -97,11 +97,11 @@ enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
 #else
 #define CRT_OCCUPANCY_ATTR
 #endif
-template <bool COUNT_WORK>
+template <bool COUNT_WORK, int SD>
 __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
                                                                        int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
-    __shared__ int lds_stack[(CRT_STACK_DEPTH + 1) * 64];
+    __shared__ int lds_stack[(SD + 1) * 64]; // SD = 16 when the BVH is at most 16 levels deep: 20 instead of 18 waves per CU
     const uint32_t lane = threadIdx.x;
     unsigned int *work = reinterpret_cast<unsigned int *>(counters + 6);
     const uint32_t NO_PIXEL = 0xFFFFFFFFu;
@@ -262,6 +262,379 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
     }
 }
 
+// =========================================================================================================
+// render_pool_kernel: the same per-path operation sequence, scheduled over a pool of pixel contexts in LDS.
+//
+// render_kernel above binds one pixel to one lane, so a phase only ever fills the lanes whose pixel happens to be in
+// that phase (32 % of the lanes of a walk step, 37 % of the lanes in the shading code on the headline scene) and the
+// kernel is bound by VALU issue.  Here a wave owns P > 64 pixel contexts whose state lives in LDS (structure of arrays,
+// one dword per field and context), and three LDS lists say what each context needs next:
+//     cam   : a camera ray (after a path ended; also "needs a pixel")
+//     shade : a surface hit to shade and scatter
+//     walk  : a ray that entered the triangle BVH and waits for a lane
+// Lanes are not bound to contexts.  The wave runs, by priority: walk steps while at least 64-REFILL lanes are walking;
+// else it retires finished walks (their hit goes back to the context; a tie is resolved here, on the lane's own stack)
+// and refills free lanes from the walk list; else a batch of up to 64 contexts of the longer of the shade / cam lists.
+// Every batch is compact, so the shading code, the camera code and the walk steps run with (nearly) full waves.
+// A context still performs exactly the sequential operation sequence of its pixel (samples in order), so the image is
+// bit-identical to render_kernel's.
+// =========================================================================================================
+enum { CF_IJ = 0, CF_PACK, CF_OX, CF_OY, CF_OZ, CF_DX, CF_DY, CF_DZ, CF_AX, CF_AY, CF_AZ, CF_CX, CF_CY, CF_CZ, CF_T, CF_CODE, CF_MAT, CF_COUNT };
+// CF_IJ: pixel column (bits 0..15) | row (16..31); 0xFFFFFFFF = no pixel.
+// CF_PACK: sample index (bits 0..15) | depth (16..23) | tag (24..31)
+enum { TAG_FETCH = 0, TAG_MISS = 1, TAG_END = 2, TAG_RUN = 3 };
+enum { DEST_NONE = 0, DEST_WALK = 1, DEST_SHADE = 2, DEST_CAM = 3 };
+#define CRT_TIE_BIT 0x40000000
+
+__device__ __forceinline__ int lane_rank(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <int P>
+struct Pool {
+    uint32_t *f; // [CF_COUNT][P]
+    __device__ __forceinline__ uint32_t u(int field, int c) const { return f[field * P + c]; }
+    __device__ __forceinline__ int i(int field, int c) const { return (int)f[field * P + c]; }
+    __device__ __forceinline__ float fl(int field, int c) const { return __uint_as_float(f[field * P + c]); }
+    __device__ __forceinline__ f3 v3(int field, int c) const { return mk3(fl(field, c), fl(field + 1, c), fl(field + 2, c)); }
+    __device__ __forceinline__ void set(int field, int c, uint32_t v) { f[field * P + c] = v; }
+    __device__ __forceinline__ void set(int field, int c, int v) { f[field * P + c] = (uint32_t)v; }
+    __device__ __forceinline__ void set(int field, int c, float v) { f[field * P + c] = __float_as_uint(v); }
+    __device__ __forceinline__ void set3(int field, int c, f3 v) { set(field, c, v.x); set(field + 1, c, v.y); set(field + 2, c, v.z); }
+};
+
+// wave-uniform list push: call in uniform control flow only (n stays in a scalar register)
+typedef unsigned short ctx_id;
+__device__ __forceinline__ void list_push(ctx_id *list, int &n, bool pred, int c)
+{
+    const unsigned long long m = __ballot(pred);
+    if (pred) list[n + lane_rank(m)] = (ctx_id)c;
+    n += popc64(m);
+}
+
+// Start of a path segment for context c (camera.h:68 world->hit): the sphere tests and the root-box test.  Writes the
+// ray and the search state to the context and says where the context goes next.
+template <int P, class Counters>
+__device__ __forceinline__ int ray_start(const SceneView &sc, Pool<P> &pool, int c, f3 o, f3 d, float tmin, uint32_t pack_run, Counters &cnt)
+{
+    cnt.ray();
+    Search s;
+    s.t = FLT_MAX; s.code = -1; s.mat = 0; s.rank = 0; s.near_tie = false;
+    trav_spheres<MODE_CLOSEST>(sc, o, d, tmin, s, 0, 0.0f, cnt);
+    Trav tv;
+    trav_root<MODE_CLOSEST>(sc, o, d, s, 0.0f, tv);
+    pool.set3(CF_OX, c, o);
+    pool.set3(CF_DX, c, d);
+    if (tv.cur != CRT_BVH_NONE || s.near_tie) { // a tie among spheres is resolved where walks retire (needs a stack)
+        pool.set(CF_T, c, s.t); pool.set(CF_CODE, c, s.code); pool.set(CF_MAT, c, s.mat | (s.near_tie ? CRT_TIE_BIT : 0));
+        pool.set(CF_PACK, c, pack_run);
+        return DEST_WALK;
+    }
+    if (s.code < 0) { // camera.h:68-71: nothing hit
+        pool.set(CF_PACK, c, (pack_run & 0x00FFFFFFu) | ((uint32_t)TAG_MISS << 24));
+        return DEST_CAM;
+    }
+    pool.set(CF_T, c, s.t); pool.set(CF_CODE, c, s.code); pool.set(CF_MAT, c, s.mat);
+    pool.set(CF_PACK, c, pack_run);
+    return DEST_SHADE;
+}
+
+// Node records: the first `ncached` nodes (breadth-first numbering = the top of the tree) from the workgroup's LDS copy,
+// the others from device memory.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const v4f *lds_q4_ptr; // keeps the LDS copy on ds_read (a generic pointer would load via flat_)
+__device__ __forceinline__ q4 to_q4(v4f v) { q4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+struct CachedNodes {
+    const q4 *global;
+    lds_q4_ptr lds;
+    int ncached;
+    __device__ __forceinline__ void fetch(int cur, q4 &n0, q4 &n1, q4 &n2, q4 &n3) const
+    {
+        if (cur < ncached) {
+            lds_q4_ptr n = lds + 4u * (uint32_t)cur;
+            n0 = to_q4(n[0]); n1 = to_q4(n[1]); n2 = to_q4(n[2]); n3 = to_q4(n[3]);
+        } else {
+            const q4 *n = global + 4u * (uint32_t)cur;
+            n0 = n[0]; n1 = n[1]; n2 = n[2]; n3 = n[3];
+        }
+    }
+};
+
+// LDS traffic between lanes of one wave needs no hardware barrier (a wave's LDS operations complete in order); this
+// only keeps the compiler from moving them across the hand-over points.
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// W waves per workgroup, each with its own pool, lists and stack; they share the LDS copy of the first NC nodes and never
+// synchronise after it is filled.
+template <bool COUNT_WORK, int P, int SD, int W, int NC>
+__global__ __launch_bounds__(64 * W) void render_pool_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
+                                                             int *__restrict__ ids, unsigned long long *__restrict__ counters)
+{
+    __shared__ q4 lds_nodes[NC > 0 ? 4 * NC : 1];
+    __shared__ int lds_stack_all[W][(SD + 1) * 64];
+    __shared__ uint32_t lds_pool_all[W][CF_COUNT * P];
+    __shared__ ctx_id l_cam_all[W][P], l_shade_all[W][P], l_walk_all[W][P];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    int *lds_stack = lds_stack_all[wave];
+    uint32_t *lds_pool = lds_pool_all[wave];
+    ctx_id *l_cam = l_cam_all[wave], *l_shade = l_shade_all[wave], *l_walk = l_walk_all[wave];
+    CachedNodes nodes;
+    nodes.global = sc.nodes; nodes.lds = (lds_q4_ptr)lds_nodes; nodes.ncached = NC > 0 ? min((int)sc.nnodes, NC) : 0;
+    if (NC > 0) {
+        for (int k = (int)threadIdx.x; k < 4 * nodes.ncached; k += 64 * W) lds_nodes[k] = sc.nodes[k];
+        __syncthreads(); // the only workgroup barrier
+    }
+    unsigned int *work = reinterpret_cast<unsigned int *>(counters + 6);
+    const uint32_t NO_PIXEL = 0xFFFFFFFFu;
+    const float tmin = 0.001f; // camera.h:68
+    const int REFILL = (int)ra.sched_threshold; // free lanes that trigger a refill / end a run of walk steps
+
+    LdsStack stack;
+    stack.init(lds_stack + lane);
+    Pool<P> pool;
+    pool.f = lds_pool;
+    typename std::conditional<COUNT_WORK, RegCounters, RayCounters>::type cnt;
+    uint32_t wc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    unsigned long long t_start = 0;
+    if constexpr (COUNT_WORK) t_start = wall_clock64();
+
+    // all contexts start by asking for a pixel
+    for (int c = (int)lane; c < P; c += 64) {
+        pool.set(CF_IJ, c, NO_PIXEL);
+        pool.set(CF_PACK, c, (uint32_t)TAG_FETCH << 24);
+        l_cam[c] = (ctx_id)c;
+    }
+    int n_cam = P, n_shade = 0, n_walkq = 0, live = P;
+    wave_fence();
+
+    // walking state of this lane
+    int my = -1;
+    f3 o = mk3(0.0f, 0.0f, 0.0f), d = o;
+    Search hit;
+    hit.t = FLT_MAX; hit.code = -1; hit.mat = 0; hit.rank = 0; hit.near_tie = false;
+    Trav tv;
+    tv.idir = tv.ood = mk3(0.0f, 0.0f, 0.0f); tv.shift = 0.0f; tv.hi = 0.0f; tv.cur = CRT_BVH_NONE;
+
+    for (uint32_t guard = 0; guard < 50000000u; guard++) { // every wave leaves this loop: all contexts retire, or the guard trips
+        const int n_walk = popc64(__ballot(tv.cur != CRT_BVH_NONE));
+        const bool others = n_walkq > 0 || n_shade > 0 || n_cam > 0;
+        if (n_walk > 0 && (n_walk >= 64 - REFILL || !others)) {
+            // ================================ walk steps ================================
+            // until REFILL lanes are free (then they are retired and refilled, or their hits are shaded)
+            const int low = max((others ? 64 : n_walk) - REFILL + (others ? 0 : 1), 1);
+            for (;;) {
+                const bool inner = is_inner(tv.cur), leaf = tv.cur < 0;
+                const int n_inner = popc64(__ballot(inner)), n_leaf = popc64(__ballot(leaf));
+                if (n_inner + n_leaf < low) break;
+                if (n_inner >= n_leaf) {
+                    if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_inner; } }
+                    if (inner) trav_inner_from(nodes, tv, stack, cnt);
+                } else {
+                    if constexpr (COUNT_WORK) { if (lane == 0) { wc[6]++; wc[7] += n_leaf; } }
+                    if (leaf) trav_leaf<MODE_CLOSEST>(sc, o, d, tmin, hit, 0, 0.0f, tv, stack, cnt);
+                }
+            }
+            continue;
+        }
+        // ================================ retire finished walks ================================
+        {
+            const bool fin = my >= 0 && tv.cur == CRT_BVH_NONE;
+            int dest = DEST_NONE;
+            const int c = my;
+            if (fin) {
+                float t = 0.0f;
+                int mat = 0;
+                const int code = resolve_hit(sc, o, d, tmin, FLT_MAX, hit, t, mat, stack, cnt); // tie fold (rare) on this lane's stack
+                if (code < 0) {
+                    pool.set(CF_PACK, c, (pool.u(CF_PACK, c) & 0x00FFFFFFu) | ((uint32_t)TAG_MISS << 24));
+                    dest = DEST_CAM;
+                } else {
+                    pool.set(CF_T, c, t); pool.set(CF_CODE, c, code); pool.set(CF_MAT, c, mat);
+                    dest = DEST_SHADE;
+                }
+                my = -1;
+            }
+            list_push(l_shade, n_shade, dest == DEST_SHADE, c);
+            list_push(l_cam, n_cam, dest == DEST_CAM, c);
+        }
+        if (n_walkq > 0) {
+            // ================================ refill free lanes from the walk list ================================
+            const bool is_free = my < 0;
+            const unsigned long long m = __ballot(is_free);
+            const int nt = min(popc64(m), n_walkq);
+            const int r = lane_rank(m);
+            if (is_free && r < nt) {
+                const int c = l_walk[n_walkq - 1 - r];
+                my = c;
+                o = pool.v3(CF_OX, c);
+                d = pool.v3(CF_DX, c);
+                const int mt = pool.i(CF_MAT, c);
+                hit.t = pool.fl(CF_T, c); hit.code = pool.i(CF_CODE, c); hit.mat = mt & ~CRT_TIE_BIT; hit.near_tie = (mt & CRT_TIE_BIT) != 0;
+                trav_root<MODE_CLOSEST>(sc, o, d, hit, 0.0f, tv);
+                stack.reset();
+            }
+            n_walkq -= nt;
+            wave_fence();
+            continue;
+        }
+        if (n_shade > 0 && n_shade >= n_cam) {
+            // ================================ shade batch ================================
+            const int nb = min(n_shade, 64);
+            const bool have = (int)lane < nb;
+            const int c = have ? l_shade[n_shade - nb + (int)lane] : 0;
+            n_shade -= nb;
+            if constexpr (COUNT_WORK) { if (lane == 0) { wc[0]++; wc[1] += nb; } }
+            int dest = DEST_NONE;
+            if (have) {
+                const f3 ro = pool.v3(CF_OX, c), rd = pool.v3(CF_DX, c);
+                const float t = pool.fl(CF_T, c);
+                const int code = pool.i(CF_CODE, c), mat = pool.i(CF_MAT, c);
+                const uint32_t pack = pool.u(CF_PACK, c);
+                const uint32_t s_idx = pack & 0xFFFFu, depth = (pack >> 16) & 0xFFu;
+                const f3 att = pool.v3(CF_AX, c);
+                const Shade m = sc.shades[mat]; // issued together with the primitive fetch: one memory round trip
+                const Surface sf = surface_at(sc, code, ro, rd, t);
+                cnt.shade();
+                const uint32_t ij = pool.u(CF_IJ, c);
+                const uint32_t pixel = (ij >> 16) * ra.width + (ij & 0xFFFFu); // renderer.h:24
+                if (depth == 0 && ids && ra.sample_offset + s_idx == ra.ids_sample) ids[pixel] = sf.prim;
+                const f3 colour = texture_value(m, sf.point);
+                if (scatters(m.type) && depth + 1 < ra.max_depth) {
+                    const u4 r = philox4x32_10(pixel, ra.sample_offset + s_idx, 1u + depth, 0u, ra.key0, ra.key1);
+                    f3 a2, no, nd;
+                    scatter(m.type, m.param, colour, rd, sf.point, sf.normal, sf.front_face, r, a2, no, nd);
+                    pool.set3(CF_AX, c, att * a2); // camera.h:82-83
+                    dest = ray_start(sc, pool, c, no, nd, tmin, s_idx | ((depth + 1u) << 16) | ((uint32_t)TAG_RUN << 24), cnt);
+                } else {
+                    // path over (camera.h:73-79): its colour is the emission seen through the attenuation; a path only
+                    // ever collects one non-zero term (lights do not scatter, material.h:14-16), so colour = fma(att, e, 0)
+                    const f3 e = emitted(m.type, colour);
+                    pool.set3(CF_AX, c, mk3(fma1(att.x, e.x, 0.0f), fma1(att.y, e.y, 0.0f), fma1(att.z, e.z, 0.0f)));
+                    pool.set(CF_PACK, c, (pack & 0x00FFFFFFu) | ((uint32_t)TAG_END << 24));
+                    dest = DEST_CAM;
+                }
+            }
+            wave_fence();
+            list_push(l_walk, n_walkq, dest == DEST_WALK, c);
+            list_push(l_shade, n_shade, dest == DEST_SHADE, c);
+            list_push(l_cam, n_cam, dest == DEST_CAM, c);
+            wave_fence();
+            continue;
+        }
+        if (n_cam > 0) {
+            // ================================ camera batch ================================
+            const int nb = min(n_cam, 64);
+            const bool have = (int)lane < nb;
+            const int c = have ? l_cam[n_cam - nb + (int)lane] : 0;
+            n_cam -= nb;
+            if constexpr (COUNT_WORK) { if (lane == 0) { wc[0]++; wc[1] += nb; wc[3]++; } }
+            uint32_t ij = NO_PIXEL, s_idx = 0;
+            bool need_pixel = false;
+            if (have) {
+                const uint32_t pack = pool.u(CF_PACK, c);
+                const uint32_t tag = pack >> 24;
+                s_idx = pack & 0xFFFFu;
+                ij = pool.u(CF_IJ, c);
+                if (tag != TAG_FETCH) { // a path ended: renderer.h:31
+                    const f3 att = pool.v3(CF_AX, c);
+                    const f3 color = tag == TAG_MISS ? mk3(fma1(att.x, cam.background.x, 0.0f), fma1(att.y, cam.background.y, 0.0f),
+                                                           fma1(att.z, cam.background.z, 0.0f))
+                                                     : att; // TAG_END: the path's colour was left in the attenuation fields
+                    pool.set3(CF_CX, c, pool.v3(CF_CX, c) + color);
+                    s_idx++;
+                }
+                need_pixel = tag == TAG_FETCH || s_idx >= ra.spp;
+                if (need_pixel && ij != NO_PIXEL) { // pixel complete
+                    const uint32_t i = ij & 0xFFFFu, j = ij >> 16;
+                    const uint32_t tile = (j >> 3) * ra.tiles_x + (i >> 3);
+                    store_pixel(ra, out, nullptr, 64u * (tile / ra.tile_ranks) + ((j & 7u) << 3 | (i & 7u)), j * ra.width + i, pool.v3(CF_CX, c), -1);
+                }
+            }
+            // pixel queue: one atomic per batch
+            const unsigned long long fm = __ballot(need_pixel);
+            bool retired = false, retry = false;
+            if (fm) {
+                unsigned int base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(fm)) base = atomicAdd(work, (unsigned int)popc64(fm));
+                base = (unsigned int)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(fm));
+                if (need_pixel) {
+                    const uint32_t q = base + (uint32_t)lane_rank(fm);
+                    if (q >= ra.local_pixels) { // queue empty: the context retires
+                        retired = true;
+                    } else {
+                        const uint32_t tile = (q >> 6) * ra.tile_ranks + ra.tile_rank, l = q & 63u;
+                        const uint32_t i = (tile % ra.tiles_x) * 8u + (l & 7u), j = (tile / ra.tiles_x) * 8u + (l >> 3);
+                        if (i < ra.width && j < ra.height) { // renderer.h:22
+                            s_idx = 0;
+                            ij = i | (j << 16);
+                            pool.set(CF_IJ, c, ij);
+                            pool.set3(CF_CX, c, mk3(0.0f, 0.0f, 0.0f));
+                        } else { // outside the image (ragged last tile column / row): nothing to render, ask again
+                            if (ra.flags & RA_COMPACT) { out[3 * (size_t)q + 0] = 0.0f; out[3 * (size_t)q + 1] = 0.0f; out[3 * (size_t)q + 2] = 0.0f; }
+                            pool.set(CF_IJ, c, NO_PIXEL);
+                            pool.set(CF_PACK, c, (uint32_t)TAG_FETCH << 24);
+                            retry = true;
+                        }
+                    }
+                }
+            }
+            live -= popc64(__ballot(retired));
+            int dest = DEST_NONE;
+            if (have && !retired) {
+                if (retry) dest = DEST_CAM;
+                else {
+                    const uint32_t i = ij & 0xFFFFu, j = ij >> 16, pixel = j * ra.width + i;
+                    const uint32_t sample = ra.sample_offset + s_idx;
+                    if (ids && sample == ra.ids_sample) ids[pixel] = -1; // until this sample's first hit says otherwise (shade batch)
+                    f3 co, cd;
+                    camera_ray(cam, i, j, pixel, sample, ra.key0, ra.key1, co, cd);
+                    pool.set3(CF_AX, c, mk3(1.0f, 1.0f, 1.0f));
+                    dest = ray_start(sc, pool, c, co, cd, tmin, s_idx | ((uint32_t)TAG_RUN << 24), cnt);
+                }
+            }
+            wave_fence();
+            list_push(l_walk, n_walkq, dest == DEST_WALK, c);
+            list_push(l_shade, n_shade, dest == DEST_SHADE, c);
+            list_push(l_cam, n_cam, dest == DEST_CAM, c);
+            wave_fence();
+            continue;
+        }
+        if (n_walk == 0 && popc64(__ballot(my >= 0)) == 0) break; // nothing listed, nothing walking, nothing to retire
+    }
+
+    const uint32_t rays = wave_sum(cnt.rays), refolds = wave_sum(cnt.refolds);
+    if (lane == 0) {
+        atomicAdd(&counters[0], (unsigned long long)rays);
+        if (refolds) atomicAdd(&counters[4], (unsigned long long)refolds);
+        if (live != 0) atomicAdd(&counters[7], 1ull); // must stay 0: a wave left with unfinished contexts (guard tripped)
+    }
+    if constexpr (COUNT_WORK) {
+        const uint32_t n = wave_sum(cnt.nodes), t = wave_sum(cnt.tris), sp = wave_sum(cnt.spheres), sh = wave_sum(cnt.shades);
+        if (lane == 0) {
+            atomicAdd(&counters[5], (unsigned long long)sh);
+            atomicAdd(&counters[1], (unsigned long long)n);
+            atomicAdd(&counters[2], (unsigned long long)t);
+            atomicAdd(&counters[3], (unsigned long long)sp);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t w = wave_sum(wc[k]);
+            if (lane == 0) atomicAdd(&counters[8 + k], (unsigned long long)w);
+        }
+        if (lane == 0 && wc[0] > 1) {
+            const unsigned long long dt = wall_clock64() - t_start;
+            atomicAdd(&counters[16], 1ull);
+            atomicAdd(&counters[17], dt);
+            atomicMax(&counters[10], dt);
+        }
+    }
+}
+
 // compact (rank-major, tile-major) -> row-major frame
 __global__ __launch_bounds__(64) void untile_kernel(const float *__restrict__ compact_all, uint32_t width, uint32_t height, uint32_t tiles_x,
                                                     uint32_t ntiles, uint32_t tile_ranks, uint32_t tiles_per_rank, float *__restrict__ out)
@@ -298,8 +671,26 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     a.local_pixels = local_tiles * 64u;
     // persistent waves: enough to fill the device; each lane keeps drawing pixels until the counter runs out
     const uint32_t blocks = local_tiles < max_waves ? local_tiles : max_waves;
-    if (count_work) hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
-    else hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
+    if (ra.kernel == RK_POOL) {
+        // Experimental (CRT_KERNEL=1).  One wave per workgroup, 96 contexts, no LDS node cache: the variant that measured
+        // best (8 waves sharing an LDS copy of the whole node array ran slower, 1.75 waves per SIMD
+        // cannot keep the VALU busy).
+#define CRT_LAUNCH_POOL(CW, PP, SD, WW, NC) \
+    hipLaunchKernelGGL((render_pool_kernel<CW, PP, SD, WW, NC>), dim3(blocks), dim3(64 * WW), 0, stream, sc, cam, a, out, ids, counters)
+        const bool shallow = ra.bvh_depth <= 16;
+        if (count_work) { if (shallow) CRT_LAUNCH_POOL(true, 96, 16, 1, 0); else CRT_LAUNCH_POOL(true, 96, 32, 1, 0); }
+        else { if (shallow) CRT_LAUNCH_POOL(false, 96, 16, 1, 0); else CRT_LAUNCH_POOL(false, 96, 32, 1, 0); }
+#undef CRT_LAUNCH_POOL
+        return hipGetLastError();
+    }
+    const bool shallow = ra.bvh_depth <= 16;
+    if (count_work) {
+        if (shallow) hipLaunchKernelGGL((render_kernel<true, 16>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
+        else hipLaunchKernelGGL((render_kernel<true, CRT_STACK_DEPTH>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
+    } else {
+        if (shallow) hipLaunchKernelGGL((render_kernel<false, 16>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
+        else hipLaunchKernelGGL((render_kernel<false, CRT_STACK_DEPTH>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
+    }
     return hipGetLastError();
 }
 

@@ -46,6 +46,7 @@ struct SceneView {
     const Sphere *spheres;
     const Shade *shades; // per material id
     int root_ref;        // BVH_NONE when there are no triangles
+    uint32_t nnodes;     // 64-byte nodes (breadth-first order: crt_bvh.cpp)
     uint32_t ntris;      // triangle slots
     uint32_t nspheres;
     f3 root_min, root_max;
@@ -157,12 +158,22 @@ CRT_HD void trav_begin(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, i
     stack.reset();
 }
 
+// Where node records come from: device memory, or (crt_kernels.hip) an LDS copy of the top of the tree.
+struct GlobalNodes {
+    const q4 *nodes;
+    CRT_HD void fetch(int cur, q4 &n0, q4 &n1, q4 &n2, q4 &n3) const
+    {
+        const q4 *n = nodes + 4u * (uint32_t)cur;
+        n0 = n[0]; n1 = n[1]; n2 = n[2]; n3 = n[3];
+    }
+};
+
 // One two-child node: both child boxes, near child next, far child pushed.  Requires is_inner(tv.cur).
-template <class Stack, class Counters>
-CRT_HD void trav_inner(const SceneView &sc, Trav &tv, Stack &stack, Counters &cnt)
+template <class Nodes, class Stack, class Counters>
+CRT_HD void trav_inner_from(const Nodes &src, Trav &tv, Stack &stack, Counters &cnt)
 {
-    const q4 *n = sc.nodes + 4u * (uint32_t)tv.cur;
-    const q4 n0 = n[0], n1 = n[1], n2 = n[2], n3 = n[3];
+    q4 n0, n1, n2, n3;
+    src.fetch(tv.cur, n0, n1, n2, n3);
     cnt.node();
     const f3 idir = tv.idir, ood = tv.ood;
     const float lo = -tv.shift, hi = tv.hi; // t >= 0 in re-based time
@@ -190,6 +201,14 @@ CRT_HD void trav_inner(const SceneView &sc, Trav &tv, Stack &stack, Counters &cn
     int next = both ? near_ref : (h0 ? r0 : r1);
     if (!h0 && !h1) next = stack.pop();
     tv.cur = next;
+}
+
+template <class Stack, class Counters>
+CRT_HD void trav_inner(const SceneView &sc, Trav &tv, Stack &stack, Counters &cnt)
+{
+    GlobalNodes src;
+    src.nodes = sc.nodes;
+    trav_inner_from(src, tv, stack, cnt);
 }
 
 // One leaf: its 1..8 triangle slots.  Requires tv.cur < 0.

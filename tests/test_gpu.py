@@ -197,3 +197,18 @@ def test_grid_scene_1m_triangles_sample(oracle, scenes, capi):
     fb, rids, _, rst = rs.render(oracle.make_camera(params, W), W, H, 1)
     assert np.array_equal(ids, rids) and np.array_equal(rgb, fb) and st.rays == rst.rays
     assert (ids >= 0).mean() > 0.5 and (ids < 999912).mean() > 0.2
+
+
+def test_context_pool_kernel_matches_default_kernel(monkeypatch, scenes, gpu_scenes):
+    """CRT_KERNEL=1 selects the experimental LDS context-pool schedule (crt_kernels.hip: render_pool_kernel): other
+    lanes render other pixels at other times, yet every pixel, id and the ray count must be identical."""
+    for name, width, height, spp, kw in [("cats", 256, 144, 8, {}), ("cat_checker", 203, 117, 5, dict(max_depth=6, ids_sample=3)),
+                                         ("cats", 64, 40, 3, dict(tile_rank=1, tile_ranks=3))]:
+        _, s = gpu_scenes(name)
+        _, cam = scenes.make_camera(width)
+        monkeypatch.delenv("CRT_KERNEL", raising=False)
+        rgb0, ids0, st0 = s.render(cam, width, height, spp, want_ids=True, **kw)
+        monkeypatch.setenv("CRT_KERNEL", "1")
+        rgb1, ids1, st1 = s.render(cam, width, height, spp, want_ids=True, **kw)
+        monkeypatch.delenv("CRT_KERNEL", raising=False)
+        assert np.array_equal(rgb0, rgb1) and np.array_equal(ids0, ids1) and st0.rays == st1.rays

@@ -15,13 +15,13 @@ for f in ["pmc_sq1", "pmc_sq2", "pmc_tcc1", "pmc_tcc2"]:
     rows = list(csv.DictReader(open(os.path.join(src, f, f + "_counter_collection.csv"))))
     agg = collections.defaultdict(list)
     for r in rows:
-        if "render_kernel<false>" in r["Kernel_Name"]:
+        if "kernel<false" in r["Kernel_Name"]:
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
             out["LDS_Block_Size"], out["Scratch_Size"], out["Grid_Size"] = r["LDS_Block_Size"], r["Scratch_Size"], r["Grid_Size"]
     for k, v in agg.items():
         out[k] = sum(v) / len(v)
 for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))):
-    if "render_kernel<false>" in r["Name"]:
+    if "kernel<false" in r["Name"]:
         out["kernel_avg_ns"], out["kernel_calls"] = float(r["AverageNs"]), int(r["Calls"])
 cycles = out["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
 out["derived"] = {
