@@ -20,6 +20,10 @@ struct LdsStack {
     __device__ __forceinline__ void reset() { top = base; }
     __device__ __forceinline__ void push(int v) { *top = v; top += 64; }
     __device__ __forceinline__ int pop() { top -= 64; return *top; }
+    // branch-free forms for the node step: the store always happens (one spare level above the deepest push takes it)
+    __device__ __forceinline__ int peek() const { return *(top - 64); }
+    __device__ __forceinline__ void push_if(int v, bool c) { *top = v; top += c ? 64 : 0; }
+    __device__ __forceinline__ void pop_if(bool c) { top -= c ? 64 : 0; }
 };
 
 struct RegCounters {
@@ -101,7 +105,7 @@ template <bool COUNT_WORK, int SD>
 __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
                                                                        int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
-    __shared__ int lds_stack[(SD + 1) * 64]; // SD = 16 when the BVH is at most 16 levels deep: 20 instead of 18 waves per CU
+    __shared__ int lds_stack[(SD + 2) * 64]; // SD = 16 when the BVH is at most 16 levels deep: 20 instead of 18 waves per CU
     const uint32_t lane = threadIdx.x;
     unsigned int *work = reinterpret_cast<unsigned int *>(counters + 6);
     const uint32_t NO_PIXEL = 0xFFFFFFFFu;
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(64 * W) void render_pool_kernel(SceneView sc, Camer
                                                              int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
     __shared__ q4 lds_nodes[NC > 0 ? 4 * NC : 1];
-    __shared__ int lds_stack_all[W][(SD + 1) * 64];
+    __shared__ int lds_stack_all[W][(SD + 2) * 64];
     __shared__ uint32_t lds_pool_all[W][CF_COUNT * P];
     __shared__ ctx_id l_cam_all[W][P], l_shade_all[W][P], l_walk_all[W][P];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;

@@ -73,14 +73,15 @@ struct Search {
     int code;
     int mat;       // material id of `code` (carried so that the shading record is fetched without waiting for the primitive)
     int rank;      // MODE_NEXT_RANK: rank of the candidate found (smallest rank > after_rank)
-    bool near_tie; // MODE_CLOSEST: two candidates within CRT_TIE_WINDOW of each other were seen
+    int near_tie;  // MODE_CLOSEST: 1 when two candidates within CRT_TIE_WINDOW of each other were seen (an int: a lane
+                   // mask would be merged with scalar instructions at every join of the walk loop)
 };
 
 template <int MODE>
 CRT_HD void offer(Search &s, float t, int code, int mat, int rank, int after_rank, float t_hi)
 {
     if (MODE == MODE_CLOSEST) {
-        if (s.code >= 0 && __builtin_fabsf(t - s.t) <= CRT_TIE_WINDOW) s.near_tie = true;
+        s.near_tie = (s.code >= 0 && __builtin_fabsf(t - s.t) <= CRT_TIE_WINDOW) ? 1 : s.near_tie;
         if (t < s.t) { s.t = t; s.code = code; s.mat = mat; }
     } else {
         if (t <= t_hi && rank > after_rank && rank < s.rank) { s.t = t; s.code = code; s.mat = mat; s.rank = rank; }
@@ -174,6 +175,7 @@ CRT_HD void trav_inner_from(const Nodes &src, Trav &tv, Stack &stack, Counters &
 {
     q4 n0, n1, n2, n3;
     src.fetch(tv.cur, n0, n1, n2, n3);
+    const int below = stack.peek(); // what a pop would return: read now, beside the node, used only if no child is hit
     cnt.node();
     const f3 idir = tv.idir, ood = tv.ood;
     const float lo = -tv.shift, hi = tv.hi; // t >= 0 in re-based time
@@ -193,14 +195,14 @@ CRT_HD void trav_inner_from(const Nodes &src, Trav &tv, Stack &stack, Counters &
                                       __builtin_fminf(__builtin_fmaxf(a1z, b1z), hi));
     const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
     const int r0 = f2i(n0.w), r1 = f2i(n1.w);
-    // branch-light selection: near child next, far child pushed; one hit: that child; none: pop
+    // branch-free selection: near child next, far child pushed; one hit: that child; none: pop
     const bool swap = tn1 < tn0;
     const int near_ref = swap ? r1 : r0, far_ref = swap ? r0 : r1;
-    const bool both = h0 && h1;
-    if (both) stack.push(far_ref);
-    int next = both ? near_ref : (h0 ? r0 : r1);
-    if (!h0 && !h1) next = stack.pop();
-    tv.cur = next;
+    const bool both = h0 && h1, none = !h0 && !h1;
+    stack.push_if(far_ref, both);
+    const int next = both ? near_ref : (h0 ? r0 : r1);
+    stack.pop_if(none);
+    tv.cur = none ? below : next;
 }
 
 template <class Stack, class Counters>

@@ -22,6 +22,10 @@ struct ArrayStack {
     void reset() { sp = 0; }
     void push(int x) { if (sp < CRT_STACK_DEPTH) v[sp] = x; sp++; if (sp > max_sp) max_sp = sp; }
     int pop() { if (sp == 0) return CRT_BVH_NONE; sp--; return v[sp]; }
+    // the kernel's branch-free forms
+    int peek() const { return sp == 0 ? CRT_BVH_NONE : v[sp - 1]; }
+    void push_if(int x, bool c) { if (c) push(x); }
+    void pop_if(bool c) { if (c && sp > 0) sp--; }
 };
 struct HostCounters {
     uint64_t nodes = 0, tris = 0, spheres = 0, rays = 0, refolds = 0;
