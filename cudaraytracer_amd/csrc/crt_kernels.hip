@@ -93,6 +93,9 @@ enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
 //      larger, until enough lanes wait for phase A again.
 // A lane's own operation sequence is exactly the sequential one (crt_traverse.h: sample_radiance), so results do not
 // depend on the schedule.  (Two pixel contexts per lane were tried and measured slower: DESIGN.md section 7.)
+#ifndef CRT_NODE_STEPS_PER_VOTE
+#define CRT_NODE_STEPS_PER_VOTE 3
+#endif
 #ifndef CRT_WAVES_PER_EU
 #define CRT_WAVES_PER_EU 5 // 512 VGPRs / 5 waves -> 96 registers per lane; the few spills this forces sit on the rare tie path
 #endif
@@ -230,6 +233,13 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                 if (n_inner >= n_leaf) {
                     if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_inner; } }
                     if (inner) trav_inner(sc, tv, stack, cnt);
+                    // more node steps on the same vote: descents come in runs, and the vote costs half a step in scalar work
+#pragma unroll
+                    for (int k = 1; k < CRT_NODE_STEPS_PER_VOTE; k++) {
+                        const bool again = is_inner(tv.cur);
+                        if constexpr (COUNT_WORK) { const int na = popc64(__ballot(inner && again)); if (lane == 0) { wc[4]++; wc[5] += na; } }
+                        if (inner && again) trav_inner(sc, tv, stack, cnt);
+                    }
                 } else {
                     if constexpr (COUNT_WORK) { if (lane == 0) { wc[6]++; wc[7] += n_leaf; } }
                     if (leaf) trav_leaf<MODE_CLOSEST>(sc, p.o, p.d, tmin, hit, 0, 0.0f, tv, stack, cnt);
