@@ -70,6 +70,25 @@ __device__ __forceinline__ void store_pixel(const RenderArgs &ra, float *__restr
 
 __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
 
+// The camera is 34 dwords of kernel argument that only the camera-ray code reads.  Left to the compiler they are loaded
+// into scalar registers at kernel entry, do not fit beside everything else and are parked in VGPR lanes: ~80
+// v_readlane per shade phase on a kernel that is bound by VALU issue.  Here they are read from the kernel-argument
+// segment where they are used (scalar loads through the constant cache); the empty asm keeps the compiler from
+// recognising the pointer and hoisting the loads back to the entry.
+struct KernelArgsLayout { SceneView sc; CameraPOD cam; RenderArgs ra; float *out; int *ids; unsigned long long *counters; };
+__device__ __forceinline__ CameraPOD load_camera_arg()
+{
+    typedef __attribute__((address_space(4))) const unsigned char *kernarg_bytes;
+    typedef __attribute__((address_space(4))) const uint32_t *kernarg_words;
+    kernarg_bytes base = (kernarg_bytes)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));
+    kernarg_words w = (kernarg_words)(base + offsetof(KernelArgsLayout, cam));
+    union { CameraPOD c; uint32_t u[sizeof(CameraPOD) / 4]; } r;
+#pragma unroll
+    for (unsigned k = 0; k < sizeof(CameraPOD) / 4; k++) r.u[k] = w[k];
+    return r.c;
+}
+
 // Lane phases while not walking (a lane walks the BVH iff tv.cur != CRT_BVH_NONE)
 enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
 
@@ -208,7 +227,8 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                     has_ray = true;
                 }
                 if (phase == P_NEW) {
-                    camera_ray(cam, i, j, pixel, ra.sample_offset + s_idx, ra.key0, ra.key1, p.o, p.d);
+                    const CameraPOD camk = load_camera_arg();
+                    camera_ray(camk, i, j, pixel, ra.sample_offset + s_idx, ra.key0, ra.key1, p.o, p.d);
                     p.attenuation = mk3(1.0f, 1.0f, 1.0f);
                     p.color = mk3(0.0f, 0.0f, 0.0f);
                     depth = 0;
