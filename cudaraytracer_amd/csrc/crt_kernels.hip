@@ -76,17 +76,18 @@ __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m)
 // segment where they are used (scalar loads through the constant cache); the empty asm keeps the compiler from
 // recognising the pointer and hoisting the loads back to the entry.
 struct KernelArgsLayout { SceneView sc; CameraPOD cam; RenderArgs ra; float *out; int *ids; unsigned long long *counters; };
-__device__ __forceinline__ CameraPOD load_camera_arg()
+template <class T>
+__device__ __forceinline__ T load_kernel_arg(size_t offset)
 {
     typedef __attribute__((address_space(4))) const unsigned char *kernarg_bytes;
     typedef __attribute__((address_space(4))) const uint32_t *kernarg_words;
     kernarg_bytes base = (kernarg_bytes)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(base));
-    kernarg_words w = (kernarg_words)(base + offsetof(KernelArgsLayout, cam));
-    union { CameraPOD c; uint32_t u[sizeof(CameraPOD) / 4]; } r;
+    kernarg_words w = (kernarg_words)(base + offset);
+    union { T v; uint32_t u[sizeof(T) / 4]; } r;
 #pragma unroll
-    for (unsigned k = 0; k < sizeof(CameraPOD) / 4; k++) r.u[k] = w[k];
-    return r.c;
+    for (unsigned k = 0; k < sizeof(T) / 4; k++) r.u[k] = w[k];
+    return r.v;
 }
 
 // Lane phases while not walking (a lane walks the BVH iff tv.cur != CRT_BVH_NONE)
@@ -195,25 +196,26 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                     }
                 }
                 if (phase == P_FETCH) {
-                    if (q != NO_PIXEL) store_pixel(ra, out, ids, q, pixel, col, primary);
+                    const RenderArgs rak = load_kernel_arg<RenderArgs>(offsetof(KernelArgsLayout, ra)); // the frame geometry is only needed here
+                    if (q != NO_PIXEL) store_pixel(rak, out, ids, q, pixel, col, primary);
                     // Raster tile order on purpose.  Measured slower: fetching one pixel ahead (+15 %: a lane then holds a
                     // pixel hostage at the end of the frame), the tiles over the mesh first (+14 %), spread evenly (+5 %),
                     // or started at the mesh's first tile row (+11 %): DESIGN.md section 7.
                     for (;;) {
                         q = atomicAdd(work, 1u);
-                        if (q >= ra.local_pixels) { q = NO_PIXEL; phase = P_DONE; break; }
-                        const uint32_t tile = (q >> 6) * ra.tile_ranks + ra.tile_rank, l = q & 63u;
-                        i = (tile % ra.tiles_x) * 8u + (l & 7u);
-                        j = (tile / ra.tiles_x) * 8u + (l >> 3);
-                        if (i < ra.width && j < ra.height) { // renderer.h:22
-                            pixel = j * ra.width + i;      // renderer.h:24
+                        if (q >= rak.local_pixels) { q = NO_PIXEL; phase = P_DONE; break; }
+                        const uint32_t tile = (q >> 6) * rak.tile_ranks + rak.tile_rank, l = q & 63u;
+                        i = (tile % rak.tiles_x) * 8u + (l & 7u);
+                        j = (tile / rak.tiles_x) * 8u + (l >> 3);
+                        if (i < rak.width && j < rak.height) { // renderer.h:22
+                            pixel = j * rak.width + i;      // renderer.h:24
                             s_idx = 0;
                             col = mk3(0.0f, 0.0f, 0.0f);
                             primary = -1;
                             phase = P_NEW;
                             break;
                         }
-                        if (ra.flags & RA_COMPACT) { out[3 * (size_t)q + 0] = 0.0f; out[3 * (size_t)q + 1] = 0.0f; out[3 * (size_t)q + 2] = 0.0f; }
+                        if (rak.flags & RA_COMPACT) { out[3 * (size_t)q + 0] = 0.0f; out[3 * (size_t)q + 1] = 0.0f; out[3 * (size_t)q + 2] = 0.0f; }
                     }
                 }
                 bool has_ray = false;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                     has_ray = true;
                 }
                 if (phase == P_NEW) {
-                    const CameraPOD camk = load_camera_arg();
+                    const CameraPOD camk = load_kernel_arg<CameraPOD>(offsetof(KernelArgsLayout, cam));
                     camera_ray(camk, i, j, pixel, ra.sample_offset + s_idx, ra.key0, ra.key1, p.o, p.d);
                     p.attenuation = mk3(1.0f, 1.0f, 1.0f);
                     p.color = mk3(0.0f, 0.0f, 0.0f);
