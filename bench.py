@@ -47,6 +47,26 @@ def algorithmic_bytes(st, width, height):
     return 64.0 * st.nodes + 48.0 * st.tri_tests + 32.0 * st.sphere_tests + 12.0 * width * height
 
 
+def pmc_traffic(workload, world):
+    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes of this same command
+    (profiles/run_rocprof.sh: FETCH_SIZE and WRITE_SIZE in their own runs; tools/summarize_prof.py applies the guide's
+    unit and gfx950 corrections).  Only valid for the default 1-GPU workload; otherwise None."""
+    if workload != "cats" or world != 1:
+        return None
+    root = os.path.join(REPO, "profiles")
+    best = None
+    for name in sorted(os.listdir(root)) if os.path.isdir(root) else []:
+        f = os.path.join(root, name, "pmc_render_kernel.json")
+        if os.path.isfile(f):
+            best = f
+    if not best:
+        return None
+    try:
+        return float(json.load(open(best))["derived"]["hbm_bytes_per_launch"])
+    except (KeyError, ValueError, OSError):
+        return None
+
+
 def cpu_baseline(desc, cam_params, width, height, max_depth, seed, target_seconds=12.0):
     """Oracle (oracle/crt_ref.c, reference traversal semantics) on the host cores: whole frame, few samples."""
     from oracle import binding as ob
@@ -165,7 +185,7 @@ def main():
                        "partition": "%s x%d" % (args.mode, world), "triangles": info.num_triangles, "bvh_nodes": info.num_nodes,
                        "rays_per_frame": int(rays_frame), "device_cus": cus},
             "roofline": {"bound": "valu", "achieved": ops / ksec / 1e12, "peak": valu_peak, "unit": "Tlane-op/s",
-                         "frac": ops / ksec / 1e12 / valu_peak, "traffic": None,
+                         "frac": ops / ksec / 1e12 / valu_peak, "traffic": pmc_traffic(args.workload, world),
                          "kernel": "render_kernel", "kernel_ms": kernel_avg_ms, "rays_per_launch": int(stw.rays),
                          "nodes_per_ray": stw.nodes / max(stw.rays, 1), "tri_tests_per_ray": stw.tri_tests / max(stw.rays, 1),
                          "hbm": {"bound": "hbm", "achieved": abytes / ksec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -105,14 +105,16 @@ enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
 //     FETCH (needs a pixel) -> NEW (needs a camera ray) -> walking -> HIT (walk over: resolve, shade, scatter) -> ...
 // and the wave alternates, by 64-bit ballots, between two phases:
 //   A  "shade", run when at least `sched_threshold` lanes are not walking (or nobody walks): HIT lanes resolve their
-//      hit, add emission and end the path or ask for scatter random numbers; finished pixels are stored and new ones
-//      fetched; NEW lanes ask for camera random numbers; ONE Philox evaluation serves both kinds; then scatter or
-//      camera ray, the sphere tests and the root-box test start the next walk.  A defocus-disk rejection
-//      (utility.h:100-109) retries in the next run with the next Philox block.
-//   B  "walk": one node step for the lanes at a node or one leaf step for the lanes at a leaf, whichever group is
-//      larger, until enough lanes wait for phase A again.
+//      hit, fetch primitive and shading record together, add emission and end the path or scatter (own Philox block);
+//      finished pixels are stored and new ones fetched; NEW lanes build the next sample's camera ray (own Philox block,
+//      defocus-disk rejection loop inline, utility.h:100-109); then the sphere tests and the root-box test start the
+//      next walk.
+//   B  "walk": node steps for the lanes at a node or one leaf step for the lanes at a leaf, whichever group is larger,
+//      until enough lanes wait for phase A again.  A vote is followed by up to CRT_NODE_STEPS_PER_VOTE node steps.
 // A lane's own operation sequence is exactly the sequential one (crt_traverse.h: sample_radiance), so results do not
-// depend on the schedule.  (Two pixel contexts per lane were tried and measured slower: DESIGN.md section 7.)
+// depend on the schedule.  The kernel is bound by VALU issue (98 % of SIMD time), so the code below
+// is written to keep scalar bookkeeping and register shuffling out of the loops; what was tried and rejected is listed
+// in DESIGN.md section 7.
 #ifndef CRT_NODE_STEPS_PER_VOTE
 #define CRT_NODE_STEPS_PER_VOTE 3
 #endif
