@@ -36,6 +36,7 @@ WORKLOADS = {
 # /opt/skills/guides/MI355X_MICROARCH.md: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (= the 157.3 TFLOP/s fp32 spec / 2)
 VALU_PEAK_TLANEOPS_256CU = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
+DEFAULT_CHUNKS = 1
 
 
 def lane_ops(st):
@@ -92,6 +93,9 @@ def main():
     ap.add_argument("--mode", choices=["tile", "sample"], default="tile")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cats")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug; invalidates the headline number)")
+    ap.add_argument("--chunks", type=int, default=-1,
+                    help="sample chunks per pixel (crt_render_params.sample_chunks): work unit = (pixel, spp/chunks samples); "
+                         "1 = whole pixel per lane, bit-exact sample-order sum; default: DEFAULT_CHUNKS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -117,8 +121,11 @@ def main():
     cam_params, cam = scenes.make_camera(W, **cam_over)
     info = scene.info()
 
+    chunks = DEFAULT_CHUNKS if args.chunks < 0 else max(args.chunks, 1)
+    while spp % chunks:
+        chunks //= 2
     if args.mode == "tile":
-        frame = TileFrame(W, H, world, rank, device)
+        frame = TileFrame(W, H, world, rank, device, sample_chunks=chunks)
 
         def launch(want_stats=False, flags=0):
             return frame.render_local(scene, cam, spp, depth, seed, want_stats=want_stats, flags=flags)
@@ -140,16 +147,20 @@ def main():
         launch()
         finish()
     barrier()
-    kernel_ms = []
-    rays_local = 0
+    # HIP events on the launch stream (= torch's current stream, handed to crt_render) around every render call of the
+    # timed region; nothing inside the region waits on the host
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        st = launch(want_stats=True)   # stats: library hipEvents around the kernel on this stream (+ one stream sync per frame)
+    for e0, e1 in events:
+        e0.record()
+        launch()
+        e1.record()
         finish()
-        kernel_ms.append(st.kernel_ms)
-        rays_local = st.rays
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in events]
+    rays_local = launch(want_stats=True).rays  # deterministic: the same frame again, outside the timed region
+    finish()
 
     t = torch.tensor([elapsed, float(rays_local), sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=device)
     if world > 1:
@@ -182,7 +193,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d %dspp depth %d (models/%s + ground + emissive sphere, seed %d)" %
                        (args.workload, W, H, spp, depth, "cat.obj" if builder != "cats" else "cats.obj", seed),
-                       "partition": "%s x%d" % (args.mode, world), "triangles": info.num_triangles, "bvh_nodes": info.num_nodes,
+                       "partition": "%s x%d" % (args.mode, world), "sample_chunks": chunks if args.mode == "tile" else 1, "triangles": info.num_triangles, "bvh_nodes": info.num_nodes,
                        "rays_per_frame": int(rays_frame), "device_cus": cus},
             "roofline": {"bound": "valu", "achieved": ops / ksec / 1e12, "peak": valu_peak, "unit": "Tlane-op/s",
                          "frac": ops / ksec / 1e12 / valu_peak, "traffic": pmc_traffic(args.workload, world),

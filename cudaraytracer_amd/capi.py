@@ -35,7 +35,7 @@ class Camera(C.Structure):  # crt_camera
 
 class RenderParams(C.Structure):  # crt_render_params
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("spp", C.c_uint32), ("sample_offset", C.c_uint32), ("max_depth", C.c_uint32),
-                ("tile_rank", C.c_uint32), ("tile_ranks", C.c_uint32), ("flags", C.c_uint32), ("ids_sample", C.c_uint32), ("reserved", C.c_uint32),
+                ("tile_rank", C.c_uint32), ("tile_ranks", C.c_uint32), ("flags", C.c_uint32), ("ids_sample", C.c_uint32), ("sample_chunks", C.c_uint32),
                 ("seed", C.c_uint64), ("stream", C.c_void_p)]
 
 
@@ -182,10 +182,10 @@ class Scene:
         return out
 
     def render(self, cam, width, height, spp, max_depth=10, seed=1984, sample_offset=0, ids_sample=0, tile_rank=0, tile_ranks=1,
-               flags=0, out_rgb=None, out_ids=None, want_ids=False, want_stats=True, stream=None):
+               flags=0, out_rgb=None, out_ids=None, want_ids=False, want_stats=True, stream=None, sample_chunks=0):
         """crt_render.  out_rgb / out_ids: numpy arrays (host) or integer device addresses; None allocates numpy outputs."""
         p = RenderParams(width=width, height=height, spp=spp, sample_offset=sample_offset, max_depth=max_depth, tile_rank=tile_rank,
-                         tile_ranks=tile_ranks, flags=flags, ids_sample=ids_sample, reserved=0, seed=seed, stream=stream)
+                         tile_ranks=tile_ranks, flags=flags, ids_sample=ids_sample, sample_chunks=sample_chunks, seed=seed, stream=stream)
         L = self._L
         rgb_np = ids_np = None
         if out_rgb is None:

@@ -150,6 +150,8 @@ struct crt_scene {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint32_t max_waves = 0; // persistent-grid size: compute units x wave slots
     SceneView view{};
+    // sample-chunk slabs (grow only): chunks x frame floats, summed in chunk order by finalize_chunks_kernel
+    float *d_chunk_slabs = nullptr; size_t chunk_slab_floats = 0;
     // staging for host-pointer renders (grow only)
     float *d_stage_rgb = nullptr; size_t stage_rgb_floats = 0;
     int *d_stage_ids = nullptr; size_t stage_ids = 0;
@@ -157,10 +159,11 @@ struct crt_scene {
     void release_device()
     {
         if (device >= 0) (void)hipSetDevice(device);
-        void *ptrs[] = { d_nodes, d_tris, d_spheres, d_shades, d_counters, d_stage_rgb, d_stage_ids };
+        void *ptrs[] = { d_nodes, d_tris, d_spheres, d_shades, d_counters, d_stage_rgb, d_stage_ids, d_chunk_slabs };
         for (void *p : ptrs) if (p) (void)hipFree(p);
         d_nodes = d_tris = d_spheres = d_shades = nullptr; d_counters = nullptr; d_stage_rgb = nullptr; d_stage_ids = nullptr;
         stage_rgb_floats = stage_ids = 0;
+        d_chunk_slabs = nullptr; chunk_slab_floats = 0;
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         ev0 = ev1 = nullptr;
@@ -432,6 +435,9 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
     if ((uint64_t)p->width * p->height > (1ull << 31)) return fail(CRT_ERR_LIMIT, "crt_render: more than 2^31 pixels");
     if (p->width > 65535u || p->height > 65535u || p->spp > 65535u || p->max_depth > 255u)
         return fail(CRT_ERR_LIMIT, "crt_render: width, height, spp must be <= 65535 and max_depth <= 255 (packed lane state)");
+    const uint32_t chunks = p->sample_chunks > 1 ? p->sample_chunks : 1u;
+    if (chunks > 1 && ((chunks & (chunks - 1u)) != 0 || p->spp % chunks != 0 || chunks > 1024u))
+        return fail(CRT_ERR_INVALID, "crt_render: sample_chunks must be a power of two (<= 1024) that divides spp");
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t stream = (hipStream_t)p->stream;
 
@@ -474,9 +480,31 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
         if (p->tile_ranks > 1) HIP_TRY(hipMemcpyAsync(d_ids, out_ids, npix * sizeof(int), hipMemcpyHostToDevice, stream));
     }
 
+    // sample chunks: the kernel writes raw chunk sums into one slab per chunk, then the slabs are added in chunk order
+    float *d_target = d_rgb;
+    ra.chunks = chunks;
+    ra.chunk_stride = (uint32_t)(rgb_floats / 3);
+    if (chunks > 1) {
+        const uint64_t units = (uint64_t)((ra.tiles_x * ra.tiles_y + ra.tile_ranks - 1) / ra.tile_ranks) * 64u * chunks;
+        if (units >= (1ull << 32)) return fail(CRT_ERR_LIMIT, "crt_render: pixels x sample_chunks does not fit the work counter");
+        const size_t need = rgb_floats * chunks;
+        if (s->chunk_slab_floats < need) {
+            if (s->d_chunk_slabs) (void)hipFree(s->d_chunk_slabs);
+            s->d_chunk_slabs = nullptr; s->chunk_slab_floats = 0;
+            HIP_TRY(hipMalloc((void **)&s->d_chunk_slabs, need * sizeof(float)));
+            s->chunk_slab_floats = need;
+        }
+        // a partial row-major render (tile_ranks > 1 without CRT_OUT_COMPACT) leaves other ranks' pixels untouched
+        if (p->tile_ranks > 1 && !(p->flags & CRT_OUT_COMPACT))
+            return fail(CRT_ERR_INVALID, "crt_render: sample_chunks with tile_ranks > 1 needs CRT_OUT_COMPACT");
+        d_target = s->d_chunk_slabs;
+        ra.flags |= (uint32_t)RA_ACCUM;
+    }
+
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, 24 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
-    HIP_TRY(launch_render(s->view, *reinterpret_cast<const CameraPOD *>(cam), ra, d_rgb, d_ids, s->d_counters, (p->flags & CRT_COUNT_WORK) != 0, s->max_waves, stream));
+    HIP_TRY(launch_render(s->view, *reinterpret_cast<const CameraPOD *>(cam), ra, d_target, d_ids, s->d_counters, (p->flags & CRT_COUNT_WORK) != 0, s->max_waves, stream));
+    if (chunks > 1) HIP_TRY(launch_finalize_chunks(s->d_chunk_slabs, chunks, rgb_floats, p->spp, (p->flags & CRT_OUT_ACCUM) != 0, d_rgb, stream));
     HIP_TRY(hipEventRecord(s->ev1, stream));
 
     if (!rgb_on_device) HIP_TRY(hipMemcpyAsync(out_rgb, d_rgb, rgb_floats * sizeof(float), hipMemcpyDeviceToHost, stream));

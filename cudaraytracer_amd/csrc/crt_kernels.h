@@ -20,6 +20,10 @@ struct RenderArgs {
     uint32_t local_pixels;    // 64 * (tiles of this rank): pixel slots handed out by the device-wide counter (set by launch_render)
     uint32_t sched_threshold; // RK_LANES: lanes that must wait for the shade/regenerate phase before it runs (1..64)
                               // RK_POOL: free lanes that end a run of walk steps (1..63)
+    uint32_t chunks;          // sample chunks per pixel (a power of two dividing spp): work unit = (pixel, chunk)
+    uint32_t chunk_shift;     // log2(chunks)                                  (set by launch_render)
+    uint32_t tiles_x_magic;   // floor(2^32 / tiles_x) for the kernel's tile -> (column, row) division (set by launch_render)
+    uint32_t chunk_stride;    // pixels per chunk slab of the scratch the kernel writes when chunks > 1
     uint32_t kernel;          // RK_*
     uint32_t bvh_depth;       // levels of the triangle BVH (selects the LDS stack size)
 };
@@ -28,6 +32,7 @@ struct RenderArgs {
 hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,
                          bool count_work, uint32_t max_waves, hipStream_t stream);
 hipError_t launch_untile(const float *compact_all, uint32_t width, uint32_t height, uint32_t tile_ranks, float *out, hipStream_t stream);
+hipError_t launch_finalize_chunks(const float *slabs, uint32_t chunks, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream);
 hipError_t launch_finalize(const float *accum, size_t n, uint32_t total_spp, float *out, hipStream_t stream);
 
 } // namespace crt

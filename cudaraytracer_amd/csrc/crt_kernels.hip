@@ -53,8 +53,10 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 }
 
 // renderer.h:36-37 + color.h:5-24: average, gamma, store (or the raw sum in accumulate mode)
+// chunk / first_sample: the part of the pixel's samples this lane rendered (sample chunks: RenderArgs.chunks > 1; then
+// the launcher has set RA_ACCUM and `out` is the chunk scratch, one frame-sized slab per chunk)
 __device__ __forceinline__ void store_pixel(const RenderArgs &ra, float *__restrict__ out, int *__restrict__ ids, uint32_t q, uint32_t pixel, f3 col,
-                                            int primary)
+                                            int primary, uint32_t chunk = 0, uint32_t first_sample = 0, uint32_t nsamples = 0xFFFFFFFFu)
 {
     f3 o = col;
     if (!(ra.flags & RA_ACCUM)) {
@@ -63,12 +65,18 @@ __device__ __forceinline__ void store_pixel(const RenderArgs &ra, float *__restr
         o.y = o.y > 0 ? __builtin_sqrtf(o.y) : 0.0f;
         o.z = o.z > 0 ? __builtin_sqrtf(o.z) : 0.0f;
     }
-    const size_t idx = (ra.flags & RA_COMPACT) ? (size_t)q : (size_t)pixel;
+    const size_t idx = (size_t)chunk * ra.chunk_stride + ((ra.flags & RA_COMPACT) ? (size_t)q : (size_t)pixel);
     out[3 * idx + 0] = o.x; out[3 * idx + 1] = o.y; out[3 * idx + 2] = o.z;
-    if (ids && ra.ids_sample >= ra.sample_offset && ra.ids_sample - ra.sample_offset < ra.spp) ids[pixel] = primary;
+    const uint32_t n = nsamples == 0xFFFFFFFFu ? ra.spp : nsamples, first = ra.sample_offset + first_sample;
+    if (ids && ra.ids_sample >= first && ra.ids_sample - first < n) ids[pixel] = primary;
 }
 
 __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
+// number of set bits of `mask` below this lane
+__device__ __forceinline__ int lane_rank(unsigned long long mask)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
 
 // The camera is 34 dwords of kernel argument that only the camera-ray code reads.  Left to the compiler they are loaded
 // into scalar registers at kernel entry, do not fit beside everything else and are parked in VGPR lanes: ~80
@@ -115,6 +123,9 @@ enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
 // depend on the schedule.  The kernel is bound by VALU issue (98 % of SIMD time), so the code below
 // is written to keep scalar bookkeeping and register shuffling out of the loops; what was tried and rejected is listed
 // in DESIGN.md section 7.
+#ifndef CRT_FETCH_BLOCK
+#define CRT_FETCH_BLOCK 16u // work units a wave takes from the device-wide counter per atomic
+#endif
 #ifndef CRT_NODE_STEPS_PER_VOTE
 #define CRT_NODE_STEPS_PER_VOTE 3
 #endif
@@ -144,7 +155,8 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
     f3 col = mk3(0.0f, 0.0f, 0.0f);
     int primary = -1, path_prim = -1;
     int phase = P_FETCH;
-    uint32_t s_idx = 0, depth = 0;
+    uint32_t blk_next = 0, blk_end = 0; // the wave's block of work units [blk_next, blk_end) (wave-uniform)
+    uint32_t s_idx = 0, s_end = 0, depth = 0; // samples [s_idx, s_end) of the pixel are still to do (s_end = spp without chunks)
     Path p;
     p.o = p.d = p.attenuation = p.color = mk3(0.0f, 0.0f, 0.0f);
     Search hit;
@@ -164,62 +176,95 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
         if (nready >= threshold || nwalk == 0) {
             // ================================ phase A ================================
             if constexpr (COUNT_WORK) { if (lane == 0) { wc[0]++; wc[1] += nready; } }
-            if (!walking && phase != P_DONE) {
-                bool want_scatter = false;
-                Surface sf;
-                sf.point = sf.normal = mk3(0.0f, 0.0f, 0.0f); sf.front_face = false; sf.prim = -1;
-                int m_type = MAT_DIFFUSE_LIGHT;
-                float m_param = 0.0f;
-                f3 colour = mk3(0.0f, 0.0f, 0.0f);
-                if (phase == P_HIT) {
-                    float t = 0.0f;
-                    int mat = 0;
-                    const int code = resolve_hit(sc, p.o, p.d, tmin, FLT_MAX, hit, t, mat, stack, cnt);
-                    if (code < 0) { // camera.h:68-71
-                        p.color = mk3(fma1(p.attenuation.x, cam.background.x, p.color.x), fma1(p.attenuation.y, cam.background.y, p.color.y),
-                                      fma1(p.attenuation.z, cam.background.z, p.color.z));
-                    } else {
-                        const Shade m = sc.shades[mat]; // issued together with the primitive fetch below: one memory round trip per hit
-                        sf = surface_at(sc, code, p.o, p.d, t);
-                        cnt.shade();
-                        if (depth == 0) path_prim = sf.prim;
-                        m_type = m.type; m_param = m.param;
-                        colour = texture_value(m, sf.point);
-                        const f3 e = emitted(m_type, colour); // camera.h:73-74
-                        p.color = mk3(fma1(p.attenuation.x, e.x, p.color.x), fma1(p.attenuation.y, e.y, p.color.y), fma1(p.attenuation.z, e.z, p.color.z));
-                        // camera.h:66,78: the scatter of the last allowed bounce cannot reach the image: not evaluated
-                        want_scatter = scatters(m_type) && depth + 1 < ra.max_depth;
-                    }
-                    if (!want_scatter) { // path over: renderer.h:31
-                        col = col + p.color;
-                        if (ra.sample_offset + s_idx == ra.ids_sample) primary = path_prim;
-                        s_idx++;
-                        phase = s_idx < ra.spp ? P_NEW : P_FETCH;
-                    }
+            const bool active = !walking && phase != P_DONE;
+            bool want_scatter = false;
+            Surface sf;
+            sf.point = sf.normal = mk3(0.0f, 0.0f, 0.0f); sf.front_face = false; sf.prim = -1;
+            int m_type = MAT_DIFFUSE_LIGHT;
+            float m_param = 0.0f;
+            f3 colour = mk3(0.0f, 0.0f, 0.0f);
+            if (active && phase == P_HIT) {
+                float t = 0.0f;
+                int mat = 0;
+                const int code = resolve_hit(sc, p.o, p.d, tmin, FLT_MAX, hit, t, mat, stack, cnt);
+                if (code < 0) { // camera.h:68-71
+                    p.color = mk3(fma1(p.attenuation.x, cam.background.x, p.color.x), fma1(p.attenuation.y, cam.background.y, p.color.y),
+                                  fma1(p.attenuation.z, cam.background.z, p.color.z));
+                } else {
+                    const Shade m = sc.shades[mat]; // issued together with the primitive fetch below: one memory round trip per hit
+                    sf = surface_at(sc, code, p.o, p.d, t);
+                    cnt.shade();
+                    if (depth == 0) path_prim = sf.prim;
+                    m_type = m.type; m_param = m.param;
+                    colour = texture_value(m, sf.point);
+                    const f3 e = emitted(m_type, colour); // camera.h:73-74
+                    p.color = mk3(fma1(p.attenuation.x, e.x, p.color.x), fma1(p.attenuation.y, e.y, p.color.y), fma1(p.attenuation.z, e.z, p.color.z));
+                    // camera.h:66,78: the scatter of the last allowed bounce cannot reach the image: not evaluated
+                    want_scatter = scatters(m_type) && depth + 1 < ra.max_depth;
                 }
-                if (phase == P_FETCH) {
-                    const RenderArgs rak = load_kernel_arg<RenderArgs>(offsetof(KernelArgsLayout, ra)); // the frame geometry is only needed here
-                    if (q != NO_PIXEL) store_pixel(rak, out, ids, q, pixel, col, primary);
+                if (!want_scatter) { // path over: renderer.h:31
+                    col = col + p.color;
+                    if (ra.sample_offset + s_idx == ra.ids_sample) primary = path_prim;
+                    s_idx++;
+                    phase = s_idx < s_end ? P_NEW : P_FETCH;
+                }
+            }
+            // ---- work queue, wave-uniform: finished units are stored, new ones come from the wave's block of the device-wide
+            // counter.  One atomic per CRT_FETCH_BLOCK units: a single address takes ~4.5 ns per atomic (measured: 8.3 M
+            // per-lane fetches alone cost 37 ms), and a wave no longer stalls on the round trip at every fetch.
+            const bool fetching = active && phase == P_FETCH;
+            const unsigned long long fm = __ballot(fetching);
+            if (fm) {
+                const RenderArgs rak = load_kernel_arg<RenderArgs>(offsetof(KernelArgsLayout, ra)); // the frame geometry is only needed here
+                const uint32_t chunk_spp = rak.spp >> rak.chunk_shift, chunk_mask = rak.chunks - 1u;
+                // q is the work index: (pixel slot << chunk_shift) | chunk
+                if (fetching && q != NO_PIXEL) {
+                    const uint32_t chunk = q & chunk_mask;
+                    store_pixel(rak, out, ids, q >> rak.chunk_shift, pixel, col, primary, chunk, chunk * chunk_spp, chunk_spp);
+                }
+                const uint32_t n_need = (uint32_t)popc64(fm), left = blk_end - blk_next, rk = (uint32_t)lane_rank(fm);
+                uint32_t fresh = 0, take = 0;
+                if (n_need > left) {
+                    take = n_need - left > CRT_FETCH_BLOCK ? n_need - left : CRT_FETCH_BLOCK;
+                    const int leader = __builtin_ctzll(fm);
+                    if ((int)lane == leader) fresh = atomicAdd(work, take);
+                    fresh = (uint32_t)__builtin_amdgcn_readlane((int)fresh, leader);
+                }
+                const uint32_t unit = rk < left ? blk_next + rk : fresh + (rk - left);
+                if (n_need > left) { blk_next = fresh + (n_need - left); blk_end = fresh + take; }
+                else blk_next += n_need;
+                if (fetching) {
                     // Raster tile order on purpose.  Measured slower: fetching one pixel ahead (+15 %: a lane then holds a
                     // pixel hostage at the end of the frame), the tiles over the mesh first (+14 %), spread evenly (+5 %),
                     // or started at the mesh's first tile row (+11 %): DESIGN.md section 7.
-                    for (;;) {
-                        q = atomicAdd(work, 1u);
-                        if (q >= rak.local_pixels) { q = NO_PIXEL; phase = P_DONE; break; }
-                        const uint32_t tile = (q >> 6) * rak.tile_ranks + rak.tile_rank, l = q & 63u;
-                        i = (tile % rak.tiles_x) * 8u + (l & 7u);
-                        j = (tile / rak.tiles_x) * 8u + (l >> 3);
+                    q = unit;
+                    if (q >= rak.local_pixels << rak.chunk_shift) { q = NO_PIXEL; phase = P_DONE; }
+                    else {
+                        const uint32_t slot = q >> rak.chunk_shift, chunk = q & chunk_mask;
+                        const uint32_t tile = (slot >> 6) * rak.tile_ranks + rak.tile_rank, l = slot & 63u;
+                        // tile / tiles_x by the host's floor(2^32 / tiles_x): at most one too small
+                        uint32_t ty = __umulhi(tile, rak.tiles_x_magic), tx = tile - ty * rak.tiles_x;
+                        if (tx >= rak.tiles_x) { tx -= rak.tiles_x; ty++; }
+                        i = tx * 8u + (l & 7u);
+                        j = ty * 8u + (l >> 3);
                         if (i < rak.width && j < rak.height) { // renderer.h:22
                             pixel = j * rak.width + i;      // renderer.h:24
-                            s_idx = 0;
+                            s_idx = chunk * chunk_spp;
+                            s_end = s_idx + chunk_spp;
                             col = mk3(0.0f, 0.0f, 0.0f);
                             primary = -1;
                             phase = P_NEW;
-                            break;
+                        } else { // outside the image (ragged last tile column / row): nothing to render, fetch again next time
+                            if (rak.flags & RA_COMPACT) {
+                                const size_t z = (size_t)chunk * rak.chunk_stride + slot;
+                                out[3 * z + 0] = 0.0f; out[3 * z + 1] = 0.0f; out[3 * z + 2] = 0.0f;
+                            }
+                            q = NO_PIXEL;
                         }
-                        if (rak.flags & RA_COMPACT) { out[3 * (size_t)q + 0] = 0.0f; out[3 * (size_t)q + 1] = 0.0f; out[3 * (size_t)q + 2] = 0.0f; }
                     }
                 }
+            }
+            if (active) {
                 bool has_ray = false;
                 if (want_scatter) {
                     const u4 r = philox4x32_10(pixel, ra.sample_offset + s_idx, 1u + depth, 0u, ra.key0, ra.key1);
@@ -324,10 +369,6 @@ enum { TAG_FETCH = 0, TAG_MISS = 1, TAG_END = 2, TAG_RUN = 3 };
 enum { DEST_NONE = 0, DEST_WALK = 1, DEST_SHADE = 2, DEST_CAM = 3 };
 #define CRT_TIE_BIT 0x40000000
 
-__device__ __forceinline__ int lane_rank(unsigned long long mask)
-{
-    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
 
 template <int P>
 struct Pool {
@@ -699,6 +740,28 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float *__restrict__
     out[k] = v > 0 ? __builtin_sqrtf(v) : 0.0f;
 }
 
+// sample chunks: out[k] = finish(((slab 0 + slab 1) + slab 2) + ...), finish = identity (raw sums) or /spp and gamma
+__global__ __launch_bounds__(256) void finalize_chunks_kernel(const float *__restrict__ slabs, uint32_t chunks, size_t n, float spp, int raw,
+                                                              float *__restrict__ out)
+{
+    const size_t k = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (k >= n) return;
+    float v = slabs[k];
+    for (uint32_t c = 1; c < chunks; c++) v = v + slabs[(size_t)c * n + k];
+    if (!raw) {
+        v = v / spp;
+        v = v > 0 ? __builtin_sqrtf(v) : 0.0f;
+    }
+    out[k] = v;
+}
+
+hipError_t launch_finalize_chunks(const float *slabs, uint32_t chunks, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream)
+{
+    const uint32_t blocks = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(finalize_chunks_kernel, dim3(blocks), dim3(256), 0, stream, slabs, chunks, n, (float)spp, raw ? 1 : 0, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,
                          bool count_work, uint32_t max_waves, hipStream_t stream)
 {
@@ -707,9 +770,14 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     if (local_tiles == 0) return hipSuccess;
     RenderArgs a = ra;
     a.local_pixels = local_tiles * 64u;
+    if (a.chunks == 0) a.chunks = 1;
+    a.chunk_shift = 0;
+    while ((1u << a.chunk_shift) < a.chunks) a.chunk_shift++;
+    a.tiles_x_magic = a.tiles_x > 1 ? (uint32_t)((1ull << 32) / a.tiles_x) : 0xFFFFFFFFu; // tiles_x == 1: tile / 1 = tile - (0 or 1), fixed up
     // persistent waves: enough to fill the device; each lane keeps drawing pixels until the counter runs out
-    const uint32_t blocks = local_tiles < max_waves ? local_tiles : max_waves;
-    if (ra.kernel == RK_POOL) {
+    const uint64_t units = (uint64_t)local_tiles * a.chunks; // wave-sized work units
+    const uint32_t blocks = units < max_waves ? (uint32_t)units : max_waves;
+    if (ra.kernel == RK_POOL && a.chunks == 1) { // (the pool kernel has no sample chunks)
         // Experimental (CRT_KERNEL=1).  One wave per workgroup, 96 contexts, no LDS node cache: the variant that measured
         // best (8 waves sharing an LDS copy of the whole node array ran slower, 1.75 waves per SIMD
         // cannot keep the VALU busy).

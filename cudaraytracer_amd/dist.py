@@ -29,8 +29,9 @@ def _device_finalize(accum, width, height, total_spp, frame):
 class TileFrame:
     """Tile-partitioned frame: render_local() -> gather() -> self.frame (on every rank)."""
 
-    def __init__(self, width, height, world, rank, device, untile_fn=None):
+    def __init__(self, width, height, world, rank, device, untile_fn=None, sample_chunks=0):
         self.width, self.height, self.world, self.rank = width, height, world, rank
+        self.sample_chunks = sample_chunks
         self.n = capi.compact_floats(width, height, world)
         self.frame = torch.zeros(height * width * 3, dtype=torch.float32, device=device)
         self.local = torch.zeros(self.n, dtype=torch.float32, device=device) if world > 1 else None
@@ -42,9 +43,10 @@ class TileFrame:
         stream = torch.cuda.current_stream(self.frame.device).cuda_stream
         if self.world == 1:
             return scene.render(cam, self.width, self.height, spp, max_depth=max_depth, seed=seed, out_rgb=self.frame.data_ptr(),
-                                want_stats=want_stats, stream=stream, flags=flags)[2]
+                                want_stats=want_stats, stream=stream, flags=flags, sample_chunks=self.sample_chunks)[2]
         return scene.render(cam, self.width, self.height, spp, max_depth=max_depth, seed=seed, tile_rank=self.rank, tile_ranks=self.world,
-                            flags=flags | capi.OUT_COMPACT, out_rgb=self.local.data_ptr(), want_stats=want_stats, stream=stream)[2]
+                            flags=flags | capi.OUT_COMPACT, out_rgb=self.local.data_ptr(), want_stats=want_stats, stream=stream,
+                            sample_chunks=self.sample_chunks)[2]
 
     def gather(self):
         if self.world == 1:

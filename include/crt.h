@@ -115,7 +115,10 @@ typedef struct crt_render_params {
     uint32_t tile_rank, tile_ranks; /* render 8x8 tiles k (row-major) with k % tile_ranks == tile_rank      */
     uint32_t flags;
     uint32_t ids_sample;          /* which sample's primary-hit ids go to out_ids                           */
-    uint32_t reserved;
+    uint32_t sample_chunks;       /* 0 or 1: a lane renders all spp samples of its pixel, summed in sample order
+                                     (renderer.h:28-32), bit for bit.  n > 1 (a power of two dividing spp): the work unit is (pixel, chunk of
+                                     spp/n consecutive samples), each chunk summed in sample order, the n chunk sums added in
+                                     order; same samples, finer load balance, sum differs by float association only       */
     uint64_t seed;                /* Philox key; reference seed literal 1984 (renderer.h:45)                */
     void *stream;                 /* hipStream_t, NULL = default stream                                     */
 } crt_render_params;

@@ -34,7 +34,7 @@ class HostSim:
 
     def render(self, scene, cam, width, height, spp, max_depth=10, seed=1984, sample_offset=0, ids_sample=0, tile_rank=0, tile_ranks=1, flags=0):
         p = capi.RenderParams(width=width, height=height, spp=spp, sample_offset=sample_offset, max_depth=max_depth, tile_rank=tile_rank,
-                              tile_ranks=tile_ranks, flags=flags, ids_sample=ids_sample, reserved=0, seed=seed, stream=None)
+                              tile_ranks=tile_ranks, flags=flags, ids_sample=ids_sample, sample_chunks=0, seed=seed, stream=None)
         out = np.zeros((height, width, 3), np.float32)
         ids = np.full((height, width), -2, np.int32)
         st = (C.c_uint64 * 6)()

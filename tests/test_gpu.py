@@ -212,3 +212,33 @@ def test_context_pool_kernel_matches_default_kernel(monkeypatch, scenes, gpu_sce
         rgb1, ids1, st1 = s.render(cam, width, height, spp, want_ids=True, **kw)
         monkeypatch.delenv("CRT_KERNEL", raising=False)
         assert np.array_equal(rgb0, rgb1) and np.array_equal(ids0, ids1) and st0.rays == st1.rays
+
+
+def test_sample_chunks_match_chunked_sum_of_oracle(oracle, scenes, gpu_scenes):
+    """sample_chunks = n: the work unit is (pixel, chunk of spp/n samples); every sample is the same, each chunk is
+    summed in sample order and the chunk sums are added in chunk order.  The oracle's raw sums per chunk, combined the
+    same way in float32, must reproduce the image bit for bit; against the unchunked image the tolerance is float
+    association only (rtol 3e-7 on the gamma-encoded value, as for the sample-split mode)."""
+    name, width, height, spp, n = "cats", 160, 90, 12, 4
+    desc, s = gpu_scenes(name)
+    params, cam = scenes.make_camera(width)
+    rgb1, ids1, st1 = s.render(cam, width, height, spp, want_ids=True, ids_sample=7)
+    rgbn, idsn, stn = s.render(cam, width, height, spp, want_ids=True, ids_sample=7, sample_chunks=n)
+    assert stn.rays == st1.rays and np.array_equal(idsn, ids1)
+    assert np.allclose(rgbn, rgb1, rtol=3e-7, atol=1e-7)
+    rs = oracle.RefScene(desc)
+    ocam = oracle.make_camera(params, width)
+    total = None
+    for c in range(n):
+        _, _, acc, _ = rs.render(ocam, width, height, spp // n, sample_offset=c * (spp // n), want_ids=False, want_accum=True)
+        total = acc.copy() if total is None else (total + acc).astype(np.float32)
+    v = (total / np.float32(spp)).astype(np.float32)
+    expect = np.where(v > 0, np.sqrt(v, dtype=np.float32), np.float32(0)).astype(np.float32)
+    assert np.array_equal(rgbn.reshape(expect.shape), expect)
+    # raw sums + compact tile lists go through the same slabs
+    from cudaraytracer_amd import capi
+    accn, _, _ = s.render(cam, width, height, spp, flags=capi.OUT_ACCUM, sample_chunks=n)
+    assert np.array_equal(accn.reshape(total.shape), total)
+    parts = [s.render(cam, width, height, spp, tile_rank=r, tile_ranks=3, flags=capi.OUT_COMPACT, sample_chunks=n)[0] for r in range(3)]
+    full = helpers.untile_numpy(np.concatenate(parts), width, height, 3)
+    assert np.array_equal(full.reshape(expect.shape), expect)
