@@ -36,7 +36,7 @@ WORKLOADS = {
 # /opt/skills/guides/MI355X_MICROARCH.md: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (= the 157.3 TFLOP/s fp32 spec / 2)
 VALU_PEAK_TLANEOPS_256CU = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
-DEFAULT_CHUNKS = 1
+DEFAULT_CHUNKS = 16
 
 
 def lane_ops(st):

@@ -322,7 +322,7 @@ extern "C" int crt_scene_commit(crt_scene *s, int device)
     if ((rc = upload(&s->d_tris, s->bvh.tris))) return rc;
     if ((rc = upload(&s->d_spheres, spheres))) return rc;
     if ((rc = upload(&s->d_shades, s->shades))) return rc;
-    HIP_TRY(hipMalloc((void **)&s->d_counters, 24 * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc((void **)&s->d_counters, CRT_COUNTER_BYTES));
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -486,7 +486,7 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
     ra.chunk_stride = (uint32_t)(rgb_floats / 3);
     if (chunks > 1) {
         const uint64_t units = (uint64_t)((ra.tiles_x * ra.tiles_y + ra.tile_ranks - 1) / ra.tile_ranks) * 64u * chunks;
-        if (units >= (1ull << 32)) return fail(CRT_ERR_LIMIT, "crt_render: pixels x sample_chunks does not fit the work counter");
+        if (units >= (1ull << 31)) return fail(CRT_ERR_LIMIT, "crt_render: pixels x sample_chunks does not fit the work counter");
         const size_t need = rgb_floats * chunks;
         if (s->chunk_slab_floats < need) {
             if (s->d_chunk_slabs) (void)hipFree(s->d_chunk_slabs);
@@ -501,7 +501,7 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
         ra.flags |= (uint32_t)RA_ACCUM;
     }
 
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 24 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, CRT_COUNTER_BYTES, stream));
     HIP_TRY(hipEventRecord(s->ev0, stream));
     HIP_TRY(launch_render(s->view, *reinterpret_cast<const CameraPOD *>(cam), ra, d_target, d_ids, s->d_counters, (p->flags & CRT_COUNT_WORK) != 0, s->max_waves, stream));
     if (chunks > 1) HIP_TRY(launch_finalize_chunks(s->d_chunk_slabs, chunks, rgb_floats, p->spp, (p->flags & CRT_OUT_ACCUM) != 0, d_rgb, stream));

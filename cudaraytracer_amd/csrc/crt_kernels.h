@@ -29,6 +29,8 @@ struct RenderArgs {
 };
 
 // counters: 24 x uint64 ([8..17] = wave-level schedule counters, crt_stats.sched) on the device: [0] rays [1] nodes [2] triangle tests [3] sphere tests [4] tie refolds [5] shaded hits [6] pixel work counter
+// bytes of the counter buffer: 32 x uint64 (the above, padded) + 64 block counters of the work queue, 256 B apart
+#define CRT_COUNTER_BYTES (32 * 8 + 64 * 256)
 hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,
                          bool count_work, uint32_t max_waves, hipStream_t stream);
 hipError_t launch_untile(const float *compact_all, uint32_t width, uint32_t height, uint32_t tile_ranks, float *out, hipStream_t stream);

@@ -124,7 +124,10 @@ enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
 // is written to keep scalar bookkeeping and register shuffling out of the loops; what was tried and rejected is listed
 // in DESIGN.md section 7.
 #ifndef CRT_FETCH_BLOCK
-#define CRT_FETCH_BLOCK 16u // work units a wave takes from the device-wide counter per atomic
+#define CRT_FETCH_BLOCK 64u // work units per block (>= 64: one block always covers a wave's request)
+#endif
+#ifndef CRT_WORK_STRIPES
+#define CRT_WORK_STRIPES 64u // block counters: an atomic on ONE address costs the device ~5 ns, and every wave waits its turn
 #endif
 #ifndef CRT_NODE_STEPS_PER_VOTE
 #define CRT_NODE_STEPS_PER_VOTE 3
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
 {
     __shared__ int lds_stack[(SD + 2) * 64]; // SD = 16 when the BVH is at most 16 levels deep: 20 instead of 18 waves per CU
     const uint32_t lane = threadIdx.x;
-    unsigned int *work = reinterpret_cast<unsigned int *>(counters + 6);
+    unsigned int *work = reinterpret_cast<unsigned int *>(counters + 32); // block counters, 64 dwords apart (crt_kernels.h)
     const uint32_t NO_PIXEL = 0xFFFFFFFFu;
     const float tmin = 0.001f; // camera.h:68
 
@@ -156,6 +159,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
     int primary = -1, path_prim = -1;
     int phase = P_FETCH;
     uint32_t blk_next = 0, blk_end = 0; // the wave's block of work units [blk_next, blk_end) (wave-uniform)
+    uint32_t stripe = blockIdx.x % CRT_WORK_STRIPES, stripes_left = CRT_WORK_STRIPES; // counter in use, counters not yet seen empty
     uint32_t s_idx = 0, s_end = 0, depth = 0; // samples [s_idx, s_end) of the pixel are still to do (s_end = spp without chunks)
     Path p;
     p.o = p.d = p.attenuation = p.color = mk3(0.0f, 0.0f, 0.0f);
@@ -209,9 +213,9 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                     phase = s_idx < s_end ? P_NEW : P_FETCH;
                 }
             }
-            // ---- work queue, wave-uniform: finished units are stored, new ones come from the wave's block of the device-wide
-            // counter.  One atomic per CRT_FETCH_BLOCK units: a single address takes ~4.5 ns per atomic (measured: 8.3 M
-            // per-lane fetches alone cost 37 ms), and a wave no longer stalls on the round trip at every fetch.
+            // ---- work queue, wave-uniform: finished units are stored, new ones come from the wave's current block.
+            // Atomics on one address are served ~5 ns apart device-wide and every wave waits its turn (measured: 2 M per
+            // frame cost 10 ms), hence blocks, and several counters.
             const bool fetching = active && phase == P_FETCH;
             const unsigned long long fm = __ballot(fetching);
             if (fm) {
@@ -222,23 +226,41 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                     const uint32_t chunk = q & chunk_mask;
                     store_pixel(rak, out, ids, q >> rak.chunk_shift, pixel, col, primary, chunk, chunk * chunk_spp, chunk_spp);
                 }
+                // Units come in blocks of CRT_FETCH_BLOCK from CRT_WORK_STRIPES counters 256 B apart; block g of counter k
+                // is global block g * stripes + k, so all counters advance through the frame in raster order together.
+                const uint32_t total = rak.local_pixels << rak.chunk_shift;
                 const uint32_t n_need = (uint32_t)popc64(fm), left = blk_end - blk_next, rk = (uint32_t)lane_rank(fm);
-                uint32_t fresh = 0, take = 0;
+                uint32_t fresh = total, fresh_end = total;
                 if (n_need > left) {
-                    take = n_need - left > CRT_FETCH_BLOCK ? n_need - left : CRT_FETCH_BLOCK;
                     const int leader = __builtin_ctzll(fm);
-                    if ((int)lane == leader) fresh = atomicAdd(work, take);
-                    fresh = (uint32_t)__builtin_amdgcn_readlane((int)fresh, leader);
+                    while (stripes_left > 0) {
+                        uint32_t b = 0;
+                        if ((int)lane == leader) b = atomicAdd(work + stripe * 64u, 1u);
+                        b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
+                        const unsigned long long lo = ((unsigned long long)b * CRT_WORK_STRIPES + stripe) * CRT_FETCH_BLOCK;
+                        if (lo < total) {
+                            fresh = (uint32_t)lo;
+                            fresh_end = total - fresh > CRT_FETCH_BLOCK ? fresh + CRT_FETCH_BLOCK : total;
+                            break;
+                        }
+                        stripe = stripe + 1u == CRT_WORK_STRIPES ? 0u : stripe + 1u; // this counter is past the end of the frame
+                        stripes_left--;
+                    }
                 }
-                const uint32_t unit = rk < left ? blk_next + rk : fresh + (rk - left);
-                if (n_need > left) { blk_next = fresh + (n_need - left); blk_end = fresh + take; }
-                else blk_next += n_need;
+                const uint32_t unit = rk < left ? blk_next + rk : fresh + (rk - left); // >= fresh_end: nothing for this lane now
+                const bool got = rk < left || unit < fresh_end;
+                if (n_need > left) {
+                    const uint32_t used = fresh + (n_need - left);
+                    blk_next = used < fresh_end ? used : fresh_end;
+                    blk_end = fresh_end;
+                } else blk_next += n_need;
+                const bool exhausted = stripes_left == 0;
                 if (fetching) {
                     // Raster tile order on purpose.  Measured slower: fetching one pixel ahead (+15 %: a lane then holds a
                     // pixel hostage at the end of the frame), the tiles over the mesh first (+14 %), spread evenly (+5 %),
                     // or started at the mesh's first tile row (+11 %): DESIGN.md section 7.
                     q = unit;
-                    if (q >= rak.local_pixels << rak.chunk_shift) { q = NO_PIXEL; phase = P_DONE; }
+                    if (!got) { q = NO_PIXEL; if (exhausted) phase = P_DONE; } // else: asks again in the next phase A
                     else {
                         const uint32_t slot = q >> rak.chunk_shift, chunk = q & chunk_mask;
                         const uint32_t tile = (slot >> 6) * rak.tile_ranks + rak.tile_rank, l = slot & 63u;
