@@ -14,6 +14,8 @@ public:
     }
     uint32_t max_depth = 10;  // camera.h:66
     uint64_t seed = 1984;     // renderer.h:45
+    uint32_t sample_chunks = 0; // 0: each pixel's samples summed in order by one lane (renderer.h:28-32, bit-exact);
+                                // a power of two dividing spp: finer work units, chunk sums added in order (include/crt.h)
     crt_stats last_stats{};
 
     // framebuffer: width*height vec3, host memory (the reference passes managed memory, kernel.cu:60) or a HIP device pointer
@@ -22,7 +24,7 @@ public:
         std::clog << "- Renderering" << std::endl; // renderer.h:65
         crt_render_params p{};
         p.width = m_width; p.height = m_height; p.spp = m_samples_per_pixel; p.max_depth = max_depth; p.seed = seed;
-        p.tile_rank = 0; p.tile_ranks = 1;
+        p.tile_rank = 0; p.tile_ranks = 1; p.sample_chunks = sample_chunks;
         checkCrtErrors(crt_render((*d_world)->scene, &(*d_camera)->pod, &p, &framebuffer[0].x, nullptr, &last_stats));
     }
 
