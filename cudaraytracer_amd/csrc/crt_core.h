@@ -274,10 +274,10 @@ CRT_HD f3 emitted(int type, f3 colour) { return type == MAT_DIFFUSE_LIGHT ? colo
 
 // camera.h:88-98 get_ray + 111-119.  Philox stage 0: block 0 = (square.x, square.y, disk0.x, disk0.y), block k>=1
 // = disk draws 2k-1 and 2k; utility.h:100-109 makes up to 10 rejection rounds and returns the 11th unconditionally.
-CRT_HD void camera_ray(const CameraPOD &cam, uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample, uint32_t k0, uint32_t k1,
-                       f3 &o, f3 &d)
+// `r` = Philox block 0 of stage 0 (the caller may have evaluated it together with other lanes' scatter blocks).
+CRT_HD void camera_ray_from(const CameraPOD &cam, uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample, uint32_t k0, uint32_t k1, u4 r,
+                            f3 &o, f3 &d)
 {
-    u4 r = philox4x32_10(pixel, sample, 0u, 0u, k0, k1);
     const float ox = fma1(u01(r.x), 0.5f - -0.5f, -0.5f);
     const float oy = fma1(u01(r.y), 0.5f - -0.5f, -0.5f);
     const f3 pixel_center = axpy(oy + (float)j, cam.pdv, axpy(ox + (float)i, cam.pdu, cam.pixel00));
@@ -301,6 +301,11 @@ CRT_HD void camera_ray(const CameraPOD &cam, uint32_t i, uint32_t j, uint32_t pi
     }
     o = origin;
     d = pixel_center - origin;
+}
+CRT_HD void camera_ray(const CameraPOD &cam, uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample, uint32_t k0, uint32_t k1,
+                       f3 &o, f3 &d)
+{
+    camera_ray_from(cam, i, j, pixel, sample, k0, k1, philox4x32_10(pixel, sample, 0u, 0u, k0, k1), o, d);
 }
 
 // The same get_ray cut at Philox block boundaries, for the kernel's scheduler: `block` 0 computes the pixel point

@@ -288,8 +288,11 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
             }
             if (active) {
                 bool has_ray = false;
+                // one Philox evaluation for both kinds of lane: stage 1 + depth for a scatter, stage 0 block 0 for a camera ray
+                u4 r;
+                r.x = r.y = r.z = r.w = 0u;
+                if (want_scatter || phase == P_NEW) r = philox4x32_10(pixel, ra.sample_offset + s_idx, want_scatter ? 1u + depth : 0u, 0u, ra.key0, ra.key1);
                 if (want_scatter) {
-                    const u4 r = philox4x32_10(pixel, ra.sample_offset + s_idx, 1u + depth, 0u, ra.key0, ra.key1);
                     f3 att, no, nd;
                     scatter(m_type, m_param, colour, p.d, sf.point, sf.normal, sf.front_face, r, att, no, nd);
                     p.attenuation = p.attenuation * att; // camera.h:82-83
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                 }
                 if (phase == P_NEW) {
                     const CameraPOD camk = load_kernel_arg<CameraPOD>(offsetof(KernelArgsLayout, cam));
-                    camera_ray(camk, i, j, pixel, ra.sample_offset + s_idx, ra.key0, ra.key1, p.o, p.d);
+                    camera_ray_from(camk, i, j, pixel, ra.sample_offset + s_idx, ra.key0, ra.key1, r, p.o, p.d);
                     p.attenuation = mk3(1.0f, 1.0f, 1.0f);
                     p.color = mk3(0.0f, 0.0f, 0.0f);
                     depth = 0;
