@@ -282,7 +282,7 @@ extern "C" int crt_scene_commit(crt_scene *s, int device)
     Box scene_box;
     reference_ranks(boxes, s->rank, scene_box);
 
-    const uint32_t max_leaf = (uint32_t)get_env_int("CRT_MAX_LEAF", 4);
+    const uint32_t max_leaf = (uint32_t)get_env_int("CRT_MAX_LEAF", 2);
     build_bvh(s->tris, s->rank, max_leaf, s->bvh);
     if (s->bvh.depth > CRT_STACK_DEPTH) return fail(CRT_ERR_LIMIT, "crt_scene_commit: BVH deeper than the traversal stack");
 
