@@ -54,7 +54,7 @@ class SceneInfo(C.Structure):  # crt_scene_info
 # every symbol include/crt.h declares (tests check that the library exports exactly these)
 SYMBOLS = ["crt_last_error", "crt_version", "crt_load_obj", "crt_free", "crt_scene_create", "crt_scene_destroy", "crt_scene_add_texture",
            "crt_scene_add_material", "crt_scene_add_mesh", "crt_scene_add_sphere", "crt_scene_commit", "crt_scene_get_info",
-           "crt_scene_get_ranks", "crt_camera_init", "crt_render", "crt_compact_floats", "crt_untile", "crt_finalize"]
+           "crt_scene_get_ranks", "crt_camera_init", "crt_render", "crt_compact_floats", "crt_untile", "crt_finalize", "crt_quantize_rgb8", "crt_write_png"]
 
 _lib = None
 
@@ -94,6 +94,8 @@ def bind(L):
     L.crt_compact_floats.restype = C.c_uint64
     L.crt_untile.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
     L.crt_finalize.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
+    L.crt_quantize_rgb8.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
+    L.crt_write_png.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_uint32]
     return L
 
 
@@ -216,3 +218,18 @@ def finalize(accum_ptr, width, height, total_spp, out_ptr, device=0, stream=None
 
 def compact_floats(width, height, tile_ranks):
     return int(lib().crt_compact_floats(width, height, tile_ranks))
+
+
+def quantize_rgb8(rgb, width, height, device=0, stream=None):
+    """crt_quantize_rgb8 (HIP kernel).  rgb: float32 numpy array (host, staged through the device) -> uint8 [H, W, 3]."""
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    out = np.empty((height, width, 3), dtype=np.uint8)
+    _check(lib().crt_quantize_rgb8(rgb.ctypes.data, width, height, out.ctypes.data, device, stream))
+    return out
+
+
+def write_png(path, rgb8):
+    """crt_write_png: uint8 [H, W, 3] -> PNG file (host code, no GPU needed)."""
+    rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w = rgb8.shape[:2]
+    _check(lib().crt_write_png(os.fsencode(path), rgb8.ctypes.data, w, h))

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <vector>
 
 #include "../../include/crt.h"
 
@@ -38,8 +39,17 @@ inline void check_crt(int result, char const *const func, const char *const file
     }
 }
 
-// reference: export_framebuffer_to_png (utility.h:122-145).  Same quantisation (x*255 clamped to [0,255], truncated);
-// written as binary PPM (the reference's stb PNG encoder is third-party code and not part of the hot path).
+// reference: export_framebuffer_to_png (utility.h:122-145): same name, same quantisation (x*255 clamped to [0,255],
+// truncated; done by the library's HIP kernel), PNG written by the library's own encoder instead of stb_image_write.
+// `framebuffer` may be host memory or a HIP device pointer.
+static inline void export_framebuffer_to_png(const vec3 *framebuffer, uint32_t width, uint32_t height, const char *filename, int device = 0)
+{
+    std::vector<uint8_t> bytes((size_t)width * height * 3);
+    checkCrtErrors(crt_quantize_rgb8(&framebuffer[0].x, width, height, bytes.data(), device, nullptr));
+    checkCrtErrors(crt_write_png(filename, bytes.data(), width, height));
+}
+
+// The same quantisation on the host, written as binary PPM (no library call: handy for diffing against the PNG).
 // `framebuffer` is a HOST pointer here: Renderer::launch_kernel_render fills host memory.
 static inline void export_framebuffer_to_ppm(const vec3 *framebuffer, uint32_t width, uint32_t height, const char *filename)
 {

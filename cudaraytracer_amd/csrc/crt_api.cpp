@@ -540,3 +540,130 @@ extern "C" int crt_finalize(const float *accum, uint32_t width, uint32_t height,
     HIP_TRY(launch_finalize(accum, (size_t)width * height * 3, total_spp, out_rgb, (hipStream_t)stream));
     return CRT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// output path (row N2): 8-bit quantisation on the device, PNG container on the host
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int crt_quantize_rgb8(const float *rgb, uint32_t width, uint32_t height, uint8_t *out_rgb8, int device, void *stream)
+{
+    if (!rgb || !out_rgb8 || width == 0 || height == 0) return fail(CRT_ERR_INVALID, "crt_quantize_rgb8: bad argument");
+    if (device < 0) return fail(CRT_ERR_NO_DEVICE, "crt_quantize_rgb8: needs a HIP device (no host path)");
+    HIP_TRY(hipSetDevice(device));
+    const size_t n = (size_t)width * height * 3;
+    const bool in_dev = is_device_pointer(rgb), out_dev = is_device_pointer(out_rgb8);
+    float *d_in = const_cast<float *>(rgb);
+    uint8_t *d_out = out_rgb8;
+    int rc = CRT_OK;
+    // host buffers are staged through the device (as crt_render does): the conversion itself always runs on the GPU
+    if (!in_dev) {
+        HIP_TRY(hipMalloc((void **)&d_in, n * sizeof(float)));
+        if (hipMemcpyAsync(d_in, rgb, n * sizeof(float), hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) rc = CRT_ERR_HIP;
+    }
+    if (rc == CRT_OK && !out_dev && hipMalloc((void **)&d_out, n) != hipSuccess) { d_out = nullptr; rc = CRT_ERR_HIP; }
+    if (rc == CRT_OK && launch_quantize(d_in, n, d_out, (hipStream_t)stream) != hipSuccess) rc = CRT_ERR_HIP;
+    if (rc == CRT_OK && !out_dev && hipMemcpyAsync(out_rgb8, d_out, n, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) rc = CRT_ERR_HIP;
+    if (!in_dev || !out_dev) {
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) rc = CRT_ERR_HIP;
+        if (!in_dev && d_in) (void)hipFree(d_in);
+        if (!out_dev && d_out) (void)hipFree(d_out);
+    }
+    if (rc != CRT_OK) return fail(rc, "crt_quantize_rgb8: HIP call failed");
+    return CRT_OK;
+}
+
+namespace {
+struct PngOut {
+    FILE *f;
+    uint32_t crc;
+    static const uint32_t *table()
+    {
+        static uint32_t t[256];
+        static bool ready = false;
+        if (!ready) {
+            for (uint32_t n = 0; n < 256; n++) {
+                uint32_t c = n;
+                for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+                t[n] = c;
+            }
+            ready = true;
+        }
+        return t;
+    }
+    bool put(const void *p, size_t n)
+    {
+        const unsigned char *b = (const unsigned char *)p;
+        const uint32_t *t = table();
+        for (size_t k = 0; k < n; k++) crc = t[(crc ^ b[k]) & 0xFFu] ^ (crc >> 8);
+        return fwrite(p, 1, n, f) == n;
+    }
+    bool be32(uint32_t v)
+    {
+        const unsigned char b[4] = { (unsigned char)(v >> 24), (unsigned char)(v >> 16), (unsigned char)(v >> 8), (unsigned char)v };
+        return put(b, 4);
+    }
+    bool begin(const char type[4], uint32_t length)
+    {
+        const unsigned char b[4] = { (unsigned char)(length >> 24), (unsigned char)(length >> 16), (unsigned char)(length >> 8), (unsigned char)length };
+        if (fwrite(b, 1, 4, f) != 4) return false;
+        crc = 0xFFFFFFFFu;
+        return put(type, 4);
+    }
+    bool end()
+    {
+        const uint32_t v = crc ^ 0xFFFFFFFFu;
+        const unsigned char b[4] = { (unsigned char)(v >> 24), (unsigned char)(v >> 16), (unsigned char)(v >> 8), (unsigned char)v };
+        return fwrite(b, 1, 4, f) == 4;
+    }
+};
+} // namespace
+
+extern "C" int crt_write_png(const char *path, const uint8_t *rgb8, uint32_t width, uint32_t height)
+{
+    if (!path || !rgb8 || width == 0 || height == 0) return fail(CRT_ERR_INVALID, "crt_write_png: bad argument");
+    const uint64_t row = 1ull + 3ull * width, raw = row * height; // filter byte + pixels
+    const uint64_t nblocks = (raw + 65534) / 65535;
+    const uint64_t idat = 2 + raw + 5 * nblocks + 4;
+    if (idat > 0x7FFFFFFFull) return fail(CRT_ERR_LIMIT, "crt_write_png: image too large for one IDAT chunk");
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(CRT_ERR_IO, "crt_write_png: cannot open output file");
+    PngOut o{ f, 0 };
+    static const unsigned char sig[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+    bool ok = fwrite(sig, 1, 8, f) == 8;
+    const unsigned char ihdr_tail[5] = { 8, 2, 0, 0, 0 }; // bit depth 8, colour type 2 (RGB), deflate, filter method 0, no interlace
+    ok = ok && o.begin("IHDR", 13) && o.be32(width) && o.be32(height) && o.put(ihdr_tail, 5) && o.end();
+    ok = ok && o.begin("IDAT", (uint32_t)idat);
+    const unsigned char zhdr[2] = { 0x78, 0x01 };
+    ok = ok && o.put(zhdr, 2);
+    // zlib stream of stored blocks over the filtered scanlines; Adler-32 of the same bytes
+    uint32_t a = 1, b = 0;
+    std::vector<unsigned char> buf;
+    buf.reserve(65535);
+    uint64_t produced = 0;
+    auto flush = [&](bool last) {
+        const uint16_t len = (uint16_t)buf.size(), nlen = (uint16_t)~len;
+        const unsigned char h[5] = { (unsigned char)(last ? 1 : 0), (unsigned char)(len & 0xFF), (unsigned char)(len >> 8), (unsigned char)(nlen & 0xFF),
+                                     (unsigned char)(nlen >> 8) };
+        ok = ok && o.put(h, 5) && (buf.empty() || o.put(buf.data(), buf.size()));
+        buf.clear();
+    };
+    auto emit = [&](const unsigned char *p, size_t n) {
+        for (size_t k = 0; k < n; k++) { a = (a + p[k]) % 65521u; b = (b + a) % 65521u; }
+        while (n) {
+            const size_t room = 65535 - buf.size(), take = n < room ? n : room;
+            buf.insert(buf.end(), p, p + take);
+            p += take; n -= take; produced += take;
+            if (buf.size() == 65535) flush(produced == raw);
+        }
+    };
+    for (uint32_t y = 0; y < height && ok; y++) {
+        const unsigned char filter0 = 0;
+        emit(&filter0, 1);
+        emit(rgb8 + (size_t)y * 3 * width, (size_t)3 * width);
+    }
+    if (!buf.empty()) flush(true);
+    ok = ok && o.be32((b << 16) | a) && o.end();
+    ok = ok && o.begin("IEND", 0) && o.end();
+    if (fclose(f) != 0) ok = false;
+    if (!ok) return fail(CRT_ERR_IO, "crt_write_png: write failed");
+    return CRT_OK;
+}

@@ -833,6 +833,30 @@ hipError_t launch_untile(const float *compact_all, uint32_t width, uint32_t heig
     return hipGetLastError();
 }
 
+// utility.h:133-137: (unsigned char) min(max(x * 255.0f, 0.0f), 255.0f); four values per lane, one dword store
+__global__ __launch_bounds__(256) void quantize_kernel(const float *__restrict__ rgb, size_t n, uint8_t *__restrict__ out)
+{
+    const size_t k4 = ((size_t)blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (k4 >= n) return;
+    uint32_t b[4] = { 0, 0, 0, 0 };
+    const uint32_t m = n - k4 < 4u ? (uint32_t)(n - k4) : 4u;
+    for (uint32_t k = 0; k < m; k++) {
+        float v = rgb[k4 + k] * 255.0f;
+        v = __builtin_fmaxf(v, 0.0f); // std::max(x, 0): a NaN x gives 0
+        v = __builtin_fminf(v, 255.0f);
+        b[k] = (uint32_t)v;
+    }
+    if (m == 4u && ((uintptr_t)(out + k4) & 3u) == 0) *reinterpret_cast<uint32_t *>(out + k4) = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+    else for (uint32_t k = 0; k < m; k++) out[k4 + k] = (uint8_t)b[k];
+}
+
+hipError_t launch_quantize(const float *rgb, size_t n, uint8_t *out, hipStream_t stream)
+{
+    const uint32_t blocks = (uint32_t)((n + 1023) / 1024);
+    hipLaunchKernelGGL(quantize_kernel, dim3(blocks), dim3(256), 0, stream, rgb, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_finalize(const float *accum, size_t n, uint32_t total_spp, float *out, hipStream_t stream)
 {
     const uint32_t blocks = (uint32_t)((n + 255) / 256);

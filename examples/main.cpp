@@ -39,7 +39,8 @@ int main(int argc, char **argv)
     std::cerr << "\nRender time: " << timer_seconds << " seconds (kernel " << renderer.last_stats.kernel_ms << " ms, " << renderer.last_stats.rays
               << " rays).\n";
 
-    export_framebuffer_to_ppm(framebuffer.data(), IMAGE_WIDTH, IMAGE_HEIGHT, "output.ppm");
+    export_framebuffer_to_png(framebuffer.data(), IMAGE_WIDTH, IMAGE_HEIGHT, "output.png"); // kernel.cu:91
+    export_framebuffer_to_ppm(framebuffer.data(), IMAGE_WIDTH, IMAGE_HEIGHT, "output.ppm"); // same bytes, host quantisation
     delete world;   // free_world<<<1,1>>> (kernel.cu:25-28,93)
     delete camera;
     return 0;

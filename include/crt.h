@@ -156,6 +156,15 @@ int crt_untile(const float *compact_all, uint32_t width, uint32_t height, uint32
  * (renderer.h:36-37, color.h:5-24).  Device pointers, in place allowed, asynchronous on `stream`. */
 int crt_finalize(const float *accum, uint32_t width, uint32_t height, uint32_t total_spp, float *out_rgb, int device, void *stream);
 
+/* ---- output path (SURVEY "next" row N2; reference: export_framebuffer_to_png, utility.h:122-145) ------------------------ */
+/* Float frame -> 8-bit RGB with the reference's quantisation: (unsigned char) min(max(x * 255.0f, 0.0f), 255.0f)
+ * (utility.h:133-137; truncation, NaN -> 0).  On the device (HIP kernel) when `device >= 0`: rgb and out_rgb8 are device
+ * pointers, asynchronous on `stream`.  There is no host path: device < 0 is an error. */
+int crt_quantize_rgb8(const float *rgb, uint32_t width, uint32_t height, uint8_t *out_rgb8, int device, void *stream);
+/* 8-bit RGB rows (host memory, row 0 = top, stride = 3 * width) -> PNG file: colour type 2, bit depth 8, filter 0,
+ * stored deflate blocks.  Replaces stb_image_write's stbi_write_png (utility.h:140); decoders return the same pixels. */
+int crt_write_png(const char *path, const uint8_t *rgb8, uint32_t width, uint32_t height);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,3 +43,5 @@ def test_reference_style_driver_matches_oracle(oracle, scenes, tmp_path):
     fb, _, _, _ = oracle.RefScene(scenes.cat()).render(oracle.make_camera(params, W), W, H, spp)
     want = np.clip(fb * np.float32(255.0), 0, 255).astype(np.uint8)   # utility.h:133-137: clamp, truncate
     assert np.array_equal(img, want)
+    from tests.test_output import decode_png
+    assert np.array_equal(decode_png(str(tmp_path / "output.png")), want)   # export_framebuffer_to_png (utility.h:122-145)
