@@ -31,6 +31,7 @@ WORKLOADS = {
     "cat_checker": ("cat_checker", 1920, 1080, 64, 8, {}),  # configs[1]
     "cat_grid": ("cat_grid", 3840, 2160, 16, 10, scenes.GRID_CAMERA),  # configs[3]
     "cats_4k": ("cats", 3840, 2160, 1024, 10, {}),       # configs[4] (use --mode sample)
+    "spheres": ("random_spheres", 1920, 1080, 64, 10, scenes.SPHERES_CAMERA),  # row N3: the reference's sphere scene (scene.h:53-90)
 }
 
 # /opt/skills/guides/MI355X_MICROARCH.md: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (= the 157.3 TFLOP/s fp32 spec / 2)
@@ -192,7 +193,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d %dspp depth %d (models/%s + ground + emissive sphere, seed %d)" %
-                       (args.workload, W, H, spp, depth, "cat.obj" if builder != "cats" else "cats.obj", seed),
+                       (args.workload, W, H, spp, depth, {"cats": "cats.obj", "random_spheres": "no mesh"}.get(builder, "cat.obj"), seed),
                        "partition": "%s x%d" % (args.mode, world), "sample_chunks": chunks if args.mode == "tile" else 1, "triangles": info.num_triangles, "bvh_nodes": info.num_nodes,
                        "rays_per_frame": int(rays_frame), "device_cus": cus},
             "roofline": {"bound": "valu", "achieved": ops / ksec / 1e12, "peak": valu_peak, "unit": "Tlane-op/s",

@@ -145,6 +145,7 @@ struct crt_scene {
     std::vector<uint32_t> rank;
     FlatBvh bvh;
     std::vector<Shade> shades; // materials joined with their textures (device record)
+    std::vector<Sphere> flat_spheres; // the spheres that are tested before the walk (the others are slots of the tree)
     void *d_nodes = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_shades = nullptr;
     unsigned long long *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -270,7 +271,6 @@ extern "C" int crt_scene_commit(crt_scene *s, int device)
 {
     if (!s) return fail(CRT_ERR_INVALID, "crt_scene_commit: null scene");
     if (s->tris.empty() && s->spheres.empty()) return fail(CRT_ERR_INVALID, "crt_scene_commit: empty scene");
-    if (s->spheres.size() > 4096) return fail(CRT_ERR_LIMIT, "crt_scene_commit: more than 4096 spheres (spheres are a flat list)");
     s->release_device();
     s->prepared = false;
 
@@ -282,16 +282,37 @@ extern "C" int crt_scene_commit(crt_scene *s, int device)
     Box scene_box;
     reference_ranks(boxes, s->rank, scene_box);
 
-    const uint32_t max_leaf = (uint32_t)get_env_int("CRT_MAX_LEAF", 2);
-    build_bvh(s->tris, s->rank, max_leaf, s->bvh);
-    if (s->bvh.depth > CRT_STACK_DEPTH) return fail(CRT_ERR_LIMIT, "crt_scene_commit: BVH deeper than the traversal stack");
-
-    std::vector<Sphere> spheres(s->spheres.size());
-    for (size_t k = 0; k < s->spheres.size(); k++) {
-        Sphere &o = spheres[k];
-        o.cx = s->spheres[k].center.x; o.cy = s->spheres[k].center.y; o.cz = s->spheres[k].center.z; o.radius = s->spheres[k].radius;
-        o.id = (int)(s->tris.size() + k); o.rank = (int)s->rank[s->tris.size() + k]; o.mat = s->spheres[k].material; o.pad = 0;
+    // Where the spheres go.  A few spheres (the reference's triangle scenes have two, scene.h:164-165) stay a flat list
+    // tested before the walk, so the r = 1000 ground never inflates the tree (F10).  A scene made of spheres
+    // (scene.h:53-90: 488 of them) puts them into the tree as sphere slots, except those far larger than the typical one.
+    std::vector<BvhSphere> tree_spheres;
+    std::vector<Sphere> &flat = s->flat_spheres;
+    flat.clear();
+    float big = FLT_MAX;
+    if (s->spheres.size() > 8) {
+        std::vector<float> radii;
+        for (const HostSphere &sp : s->spheres) radii.push_back(sp.radius);
+        std::nth_element(radii.begin(), radii.begin() + (long)(radii.size() / 2), radii.end());
+        big = 16.0f * radii[radii.size() / 2];
     }
+    for (size_t k = 0; k < s->spheres.size(); k++) {
+        const HostSphere &sp = s->spheres[k];
+        const uint32_t id = (uint32_t)(s->tris.size() + k), rank = s->rank[s->tris.size() + k];
+        if (s->spheres.size() > 8 && sp.radius <= big) {
+            tree_spheres.push_back(BvhSphere{ sp, id, rank });
+        } else {
+            Sphere o;
+            o.cx = sp.center.x; o.cy = sp.center.y; o.cz = sp.center.z; o.radius = sp.radius;
+            o.id = (int)id; o.rank = (int)rank; o.mat = sp.material; o.pad = 0;
+            flat.push_back(o);
+        }
+    }
+    if (flat.size() > 4096) return fail(CRT_ERR_LIMIT, "crt_scene_commit: more than 4096 spheres outside the tree");
+    const std::vector<Sphere> &spheres = flat;
+
+    const uint32_t max_leaf = (uint32_t)get_env_int("CRT_MAX_LEAF", 2);
+    build_bvh(s->tris, s->rank, tree_spheres, max_leaf, s->bvh);
+    if (s->bvh.depth > CRT_STACK_DEPTH) return fail(CRT_ERR_LIMIT, "crt_scene_commit: BVH deeper than the traversal stack");
 
     s->shades.assign(s->mats.size(), Shade{});
     for (size_t k = 0; k < s->mats.size(); k++) {
@@ -334,7 +355,7 @@ extern "C" int crt_scene_commit(crt_scene *s, int device)
     SceneView &v = s->view;
     v.nodes = (const q4 *)s->d_nodes; v.tris = (const q4 *)s->d_tris; v.spheres = (const Sphere *)s->d_spheres;
     v.shades = (const Shade *)s->d_shades;
-    v.root_ref = s->bvh.root_ref; v.nnodes = (uint32_t)(s->bvh.nodes.size() / 4); v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size();
+    v.root_ref = s->bvh.root_ref; v.nnodes = (uint32_t)(s->bvh.nodes.size() / 4); v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size(); v.sphere_slots = tree_spheres.empty() ? 0u : 1u;
     v.root_min = s->bvh.root_box.mn; v.root_max = s->bvh.root_box.mx;
     s->committed = true;
     return CRT_OK;
@@ -350,7 +371,7 @@ extern "C" int crt_scene_get_info(const crt_scene *s, crt_scene_info *info)
     info->num_nodes = (uint32_t)(s->bvh.nodes.size() / 4); info->bvh_depth = s->bvh.depth; info->max_leaf_size = s->bvh.max_leaf;
     info->device = s->committed ? (uint32_t)s->device : UINT32_MAX;
     info->node_bytes = s->bvh.nodes.size() * sizeof(q4); info->triangle_bytes = s->bvh.tris.size() * sizeof(q4);
-    info->sphere_bytes = s->spheres.size() * sizeof(Sphere);
+    info->sphere_bytes = s->flat_spheres.size() * sizeof(Sphere);
     info->bounds_min[0] = s->bvh.root_box.mn.x; info->bounds_min[1] = s->bvh.root_box.mn.y; info->bounds_min[2] = s->bvh.root_box.mn.z;
     info->bounds_max[0] = s->bvh.root_box.mx.x; info->bounds_max[1] = s->bvh.root_box.mx.y; info->bounds_max[2] = s->bvh.root_box.mx.z;
     return CRT_OK;

@@ -108,13 +108,15 @@ struct Ref { Box box; double c[3]; uint32_t tri; };
 struct Builder {
     const std::vector<HostTriangle> &tris;
     const std::vector<uint32_t> &rank;
+    const std::vector<BvhSphere> &spheres; // Ref.tri >= tris.size() names spheres[Ref.tri - tris.size()]
     uint32_t max_leaf;
     std::vector<Ref> refs;
     FlatBvh &out;
     static constexpr int NBINS = 16;
     static constexpr double NODE_COST = 1.0, TRI_COST = 1.3;
 
-    Builder(const std::vector<HostTriangle> &t, const std::vector<uint32_t> &r, uint32_t ml, FlatBvh &o) : tris(t), rank(r), max_leaf(ml), out(o) {}
+    Builder(const std::vector<HostTriangle> &t, const std::vector<uint32_t> &r, const std::vector<BvhSphere> &sp, uint32_t ml, FlatBvh &o)
+        : tris(t), rank(r), spheres(sp), max_leaf(ml), out(o) {}
 
     static DBox to_d(const Box &b)
     {
@@ -134,6 +136,15 @@ struct Builder {
     {
         const uint32_t first = (uint32_t)(out.tris.size() / 3);
         for (size_t i = lo; i < hi; i++) {
+            if (refs[i].tri >= tris.size()) { // sphere slot
+                const BvhSphere &sp = spheres[refs[i].tri - tris.size()];
+                q4 a, b, c;
+                a.x = sp.s.center.x; a.y = sp.s.center.y; a.z = sp.s.center.z; b.x = sp.s.radius; b.y = b.z = 0.0f; c.x = c.y = c.z = 0.0f;
+                const int id = (int)sp.id, rk = (int)(sp.rank | CRT_SPHERE_SLOT), mat = sp.s.material;
+                std::memcpy(&a.w, &id, 4); std::memcpy(&b.w, &rk, 4); std::memcpy(&c.w, &mat, 4);
+                out.tris.push_back(a); out.tris.push_back(b); out.tris.push_back(c);
+                continue;
+            }
             const HostTriangle &t = tris[refs[i].tri];
             q4 a, b, c;
             a.x = t.a.x; a.y = t.a.y; a.z = t.a.z; b.x = t.b.x; b.y = t.b.y; b.z = t.b.z; c.x = t.c.x; c.y = t.c.y; c.z = t.c.z;
@@ -238,10 +249,11 @@ struct Builder {
 
 } // namespace
 
-void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t> &rank, uint32_t max_leaf, FlatBvh &out)
+void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t> &rank, const std::vector<BvhSphere> &spheres, uint32_t max_leaf,
+               FlatBvh &out)
 {
     out = FlatBvh();
-    if (tris.empty()) return;
+    if (tris.empty() && spheres.empty()) return;
     max_leaf = std::min(std::max(max_leaf, 1u), 8u);
     // Rounding margin of the pruning slab test (crt_traverse.h): the ray origin is re-based to the root box, so
     // plane times carry an absolute error of a few ulp of the largest coordinate; 2^-18 * max|coord| covers it
@@ -251,11 +263,21 @@ void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t
         const float v[9] = { t.a.x, t.a.y, t.a.z, t.b.x, t.b.y, t.b.z, t.c.x, t.c.y, t.c.z };
         for (float f : v) maxabs = fmaxf(maxabs, fabsf(f));
     }
+    for (const BvhSphere &sp : spheres) {
+        const float r = fmaxf(sp.s.radius, fabsf(sp.s.radius_arg));
+        maxabs = fmaxf(maxabs, fmaxf(fmaxf(fabsf(sp.s.center.x), fabsf(sp.s.center.y)), fabsf(sp.s.center.z)) + r);
+    }
     const float margin = fmaxf(1e-5f, maxabs * 3.814697265625e-06f);
-    Builder b(tris, rank, max_leaf, out);
-    b.refs.resize(tris.size());
-    for (size_t i = 0; i < tris.size(); i++) {
-        Box bx = reference_triangle_box(tris[i]);
+    Builder b(tris, rank, spheres, max_leaf, out);
+    b.refs.resize(tris.size() + spheres.size());
+    for (size_t i = 0; i < b.refs.size(); i++) {
+        Box bx;
+        if (i < tris.size()) bx = reference_triangle_box(tris[i]);
+        else { // every point of the sphere (radius = max(0, argument), sphere.h:11) and the reference's own box
+            const HostSphere &sp = spheres[i - tris.size()].s;
+            const float r = fmaxf(sp.radius, fabsf(sp.radius_arg));
+            bx.mn = sp.center - mk3(r, r, r); bx.mx = sp.center + mk3(r, r, r);
+        }
         bx.mn = bx.mn - mk3(margin, margin, margin);
         bx.mx = bx.mx + mk3(margin, margin, margin);
         b.refs[i].box = bx;
@@ -263,9 +285,9 @@ void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t
         b.refs[i].c[2] = 0.5 * ((double)bx.mn.z + bx.mx.z);
         b.refs[i].tri = (uint32_t)i;
     }
-    out.nodes.reserve(4 * tris.size());
-    out.tris.reserve(3 * tris.size());
-    out.root_ref = b.build(0, tris.size(), CRT_STACK_DEPTH, 1, out.root_box);
+    out.nodes.reserve(4 * b.refs.size());
+    out.tris.reserve(3 * b.refs.size());
+    out.root_ref = b.build(0, b.refs.size(), CRT_STACK_DEPTH, 1, out.root_box);
 
     // Breadth-first node numbering: node index < N  <=>  one of the N nodes nearest the root, so "the top of the tree"
     // is a prefix of the array (the kernels keep that prefix in LDS).  Triangle slots keep their depth-first order.

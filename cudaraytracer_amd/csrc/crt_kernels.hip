@@ -26,7 +26,9 @@ struct LdsStack {
     __device__ __forceinline__ void pop_if(bool c) { top -= c ? 64 : 0; }
 };
 
+template <bool SS>
 struct RegCounters {
+    static constexpr bool sphere_slots = SS;
     uint32_t nodes = 0, tris = 0, spheres = 0, rays = 0, refolds = 0, shades = 0;
     __device__ __forceinline__ void node() { nodes++; }
     __device__ __forceinline__ void tri() { tris++; }
@@ -35,7 +37,9 @@ struct RegCounters {
     __device__ __forceinline__ void refold() { refolds++; }
     __device__ __forceinline__ void shade() { shades++; }
 };
+template <bool SS>
 struct RayCounters { // always-on: rays and tie refolds only
+    static constexpr bool sphere_slots = SS;
     uint32_t rays = 0, refolds = 0;
     __device__ __forceinline__ void node() {}
     __device__ __forceinline__ void tri() {}
@@ -140,7 +144,7 @@ enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
 #else
 #define CRT_OCCUPANCY_ATTR
 #endif
-template <bool COUNT_WORK, int SD>
+template <bool COUNT_WORK, int SD, bool SS>
 __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
                                                                        int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
 
     LdsStack stack;
     stack.init(lds_stack + lane);
-    typename std::conditional<COUNT_WORK, RegCounters, RayCounters>::type cnt;
+    typename std::conditional<COUNT_WORK, RegCounters<SS>, RayCounters<SS>>::type cnt;
 
     uint32_t q = NO_PIXEL, i = 0, j = 0, pixel = 0;
     f3 col = mk3(0.0f, 0.0f, 0.0f);
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                                   fma1(p.attenuation.z, cam.background.z, p.color.z));
                 } else {
                     const Shade m = sc.shades[mat]; // issued together with the primitive fetch below: one memory round trip per hit
-                    sf = surface_at(sc, code, p.o, p.d, t);
+                    sf = surface_at<SS>(sc, code, p.o, p.d, t);
                     cnt.shade();
                     if (depth == 0) path_prim = sf.prim;
                     m_type = m.type; m_param = m.param;
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(64 * W) void render_pool_kernel(SceneView sc, Camer
     stack.init(lds_stack + lane);
     Pool<P> pool;
     pool.f = lds_pool;
-    typename std::conditional<COUNT_WORK, RegCounters, RayCounters>::type cnt;
+    typename std::conditional<COUNT_WORK, RegCounters<true>, RayCounters<true>>::type cnt;
     uint32_t wc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long t_start = 0;
     if constexpr (COUNT_WORK) t_start = wall_clock64();
@@ -814,14 +818,13 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
 #undef CRT_LAUNCH_POOL
         return hipGetLastError();
     }
-    const bool shallow = ra.bvh_depth <= 16;
-    if (count_work) {
-        if (shallow) hipLaunchKernelGGL((render_kernel<true, 16>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
-        else hipLaunchKernelGGL((render_kernel<true, CRT_STACK_DEPTH>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
-    } else {
-        if (shallow) hipLaunchKernelGGL((render_kernel<false, 16>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
-        else hipLaunchKernelGGL((render_kernel<false, CRT_STACK_DEPTH>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
-    }
+    const bool shallow = ra.bvh_depth <= 16, ss = sc.sphere_slots != 0;
+#define CRT_LAUNCH(CW, SD, SS) hipLaunchKernelGGL((render_kernel<CW, SD, SS>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters)
+#define CRT_LAUNCH_SS(CW, SD) do { if (ss) CRT_LAUNCH(CW, SD, true); else CRT_LAUNCH(CW, SD, false); } while (0)
+    if (count_work) { if (shallow) CRT_LAUNCH_SS(true, 16); else CRT_LAUNCH_SS(true, CRT_STACK_DEPTH); }
+    else { if (shallow) CRT_LAUNCH_SS(false, 16); else CRT_LAUNCH_SS(false, CRT_STACK_DEPTH); }
+#undef CRT_LAUNCH_SS
+#undef CRT_LAUNCH
     return hipGetLastError();
 }
 

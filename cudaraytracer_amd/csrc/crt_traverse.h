@@ -48,15 +48,22 @@ struct SceneView {
     int root_ref;        // BVH_NONE when there are no triangles
     uint32_t nnodes;     // 64-byte nodes (breadth-first order: crt_bvh.cpp)
     uint32_t ntris;      // triangle slots
-    uint32_t nspheres;
+    uint32_t nspheres;   // flat list
+    uint32_t sphere_slots; // != 0: some slots of `tris` hold spheres (picks the kernel variant that tests for them)
     f3 root_min, root_max;
 };
 
 #define CRT_BVH_NONE 0x7FFFFFFF
+// bit 30 of a slot's rank word: the slot holds a sphere ([centre, id][radius, -, -, rank][-, -, -, material]); the same
+// bit in a hit code says "sphere slot" (codes: triangle slot < ntris <= flat sphere < 2^30 <= sphere slot)
+#define CRT_SPHERE_SLOT 0x40000000
 #define CRT_TIE_WINDOW 1e-6f
 #define CRT_STACK_DEPTH 32 // crt_bvh.cpp keeps the tree depth below this
 
+// A counters type also says, at compile time, whether leaves may hold sphere slots: triangle-only scenes (every BASELINE
+// configuration) run kernels without that test (it costs 7 % on the headline frame when compiled in).
 struct NoCounters {
+    static constexpr bool sphere_slots = true;
     CRT_HD void node() {}
     CRT_HD void tri() {}
     CRT_HD void sphere() {}
@@ -223,9 +230,18 @@ CRT_HD void trav_leaf(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, in
         const q4 *tp = sc.tris + 3u * (first + k);
         const q4 ta = tp[0], tb = tp[1], tc = tp[2];
         float t;
+        const int rank_word = f2i(tb.w);
+        if (Counters::sphere_slots && (rank_word & CRT_SPHERE_SLOT)) { // only in scenes whose spheres went into the tree
+            cnt.sphere();
+            if (sphere_t(mk3(ta.x, ta.y, ta.z), tb.x, o, d, tmin, t)) {
+                offer<MODE>(s, t, (int)(first + k) | CRT_SPHERE_SLOT, f2i(tc.w), rank_word & ~CRT_SPHERE_SLOT, after_rank, t_hi);
+                if (MODE == MODE_CLOSEST) tv.hi = s.t - tv.shift + CRT_TIE_WINDOW;
+            }
+            continue;
+        }
         cnt.tri();
         if (triangle_t(mk3(ta.x, ta.y, ta.z), mk3(tb.x, tb.y, tb.z), mk3(tc.x, tc.y, tc.z), o, d, tmin, t)) {
-            offer<MODE>(s, t, (int)(first + k), f2i(tc.w), f2i(tb.w), after_rank, t_hi);
+            offer<MODE>(s, t, (int)(first + k), f2i(tc.w), rank_word, after_rank, t_hi);
             if (MODE == MODE_CLOSEST) tv.hi = s.t - tv.shift + CRT_TIE_WINDOW;
         }
     }
@@ -285,6 +301,7 @@ CRT_HD int closest_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, 
 // (triangle.h:78-83, sphere.h:43-47, hittable.h:18-21).
 struct Surface { f3 point, normal; bool front_face; int prim; };
 
+template <bool SPHERE_SLOTS = true>
 CRT_HD Surface surface_at(const SceneView &sc, int code, f3 o, f3 d, float t)
 {
     Surface r;
@@ -295,6 +312,12 @@ CRT_HD Surface surface_at(const SceneView &sc, int code, f3 o, f3 d, float t)
         const f3 a = mk3(ta.x, ta.y, ta.z);
         const f3 n = normalize(cross(mk3(tb.x, tb.y, tb.z) - a, mk3(tc.x, tc.y, tc.z) - a));
         r.normal = face_normal(d, n, r.front_face);
+        r.prim = f2i(ta.w);
+    } else if (SPHERE_SLOTS && (code & CRT_SPHERE_SLOT)) {
+        const q4 *tp = sc.tris + 3 * (size_t)(code & ~CRT_SPHERE_SLOT);
+        const q4 ta = tp[0], tb = tp[1];
+        const f3 outward = div3(r.point - mk3(ta.x, ta.y, ta.z), tb.x); // sphere.h:45
+        r.normal = face_normal(d, outward, r.front_face);
         r.prim = f2i(ta.w);
     } else {
         const Sphere sp = sc.spheres[(uint32_t)code - sc.ntris];

@@ -30,7 +30,11 @@ def make_camera(width, **overrides):
     p = dict(REF_CAMERA)
     p.update(overrides)
     p.setdefault("focus_dist", focus_distance(p["lookfrom"]))
-    return p, capi.camera(width, p["lookfrom"], p["lookat"], p["vup"], p["vfov"], p["aspect"], p["defocus_angle"], p["focus_dist"])
+    cam = capi.camera(width, p["lookfrom"], p["lookat"], p["vup"], p["vfov"], p["aspect"], p["defocus_angle"], p["focus_dist"])
+    if p.get("background") is not None:  # Camera::background is a public member (camera.h:23), default (0,0,0)
+        for k in range(3):
+            cam.background[k] = float(p["background"][k])
+    return p, cam
 
 
 def _base():
@@ -103,6 +107,44 @@ def cat_grid(instances=1366, side=37, pitch=3.5, path=None):
 
 # camera for config 4: the reference direction of view, pulled back along it to frame the 130-unit grid
 GRID_CAMERA = dict(lookfrom=(80.0, 50.0, -60.0), lookat=(-4.0, 0.0, 4.0))
+
+
+def random_spheres(seed=1984):
+    """Row N3: the reference's sphere scene (kernel_create_world, scene.h:53-90): ground sphere, a 22 x 22 field of r = 0.2
+    spheres (80 % Lambertian(RND*RND), 15 % Metal(0.5(1+RND), fuzz 0.5 RND), 5 % Dielectric(1.5)) and three r = 1
+    spheres, 488 in all, no triangles.  The reference draws RND = curand_uniform from one XORWOW state; here the draws
+    come, in the same order, from numpy's Philox generator keyed on `seed` (same distribution, (0,1], other numbers)."""
+    rng = np.random.Generator(np.random.Philox(key=seed))
+
+    def rnd():
+        return float(np.float32(1.0) - np.float32(rng.random(dtype=np.float32)))  # (0, 1]
+
+    d = _base()
+
+    def sphere(center, radius, mtype, rgb, param):
+        d["materials"].append(dict(type=mtype, rgb=tuple(float(np.float32(c)) for c in rgb), param=float(np.float32(param)), texture=None))
+        d["spheres"].append(dict(center=tuple(float(np.float32(c)) for c in center), radius=float(np.float32(radius)), material=len(d["materials"]) - 1))
+
+    sphere((0.0, -1000.0, -1.0), 1000.0, capi.MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0.0)
+    for a in range(-11, 11):
+        for b in range(-11, 11):
+            choose = rnd()
+            center = (a + rnd(), 0.2, b + rnd())
+            if choose < 0.8:
+                sphere(center, 0.2, capi.MAT_LAMBERTIAN, (rnd() * rnd(), rnd() * rnd(), rnd() * rnd()), 0.0)
+            elif choose < 0.95:
+                sphere(center, 0.2, capi.MAT_METAL, (0.5 * (1.0 + rnd()), 0.5 * (1.0 + rnd()), 0.5 * (1.0 + rnd())), 0.5 * rnd())
+            else:
+                sphere(center, 0.2, capi.MAT_DIELECTRIC, (1.0, 1.0, 1.0), 1.5)
+    sphere((0.0, 1.0, 0.0), 1.0, capi.MAT_DIELECTRIC, (1.0, 1.0, 1.0), 1.5)
+    sphere((-4.0, 1.0, 0.0), 1.0, capi.MAT_LAMBERTIAN, (0.4, 0.2, 0.1), 0.0)
+    sphere((4.0, 1.0, 0.0), 1.0, capi.MAT_METAL, (0.7, 0.6, 0.5), 0.0)
+    return d
+
+
+# camera for the sphere scene: the book's view of it; the reference's Camera::background stays a member one can set, and
+# with its default (0,0,0) and no light in this scene the frame would be black, so a sky colour is used
+SPHERES_CAMERA = dict(lookfrom=(13.0, 2.0, 3.0), lookat=(0.0, 0.0, 0.0), vfov=20.0, background=(0.7, 0.8, 1.0))
 
 
 def build(desc, device=0):

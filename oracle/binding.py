@@ -125,8 +125,13 @@ class RefCamera:
 
 def make_camera(params, width):
     """params: the dict returned by cudaraytracer_amd.scenes.make_camera."""
-    return RefCamera(width, params["lookfrom"], params["lookat"], params["vup"], params["vfov"], params["aspect"], params["defocus_angle"],
-                     params["focus_dist"])
+    cam = RefCamera(width, params["lookfrom"], params["lookat"], params["vup"], params["vfov"], params["aspect"], params["defocus_angle"],
+                    params["focus_dist"])
+    if params.get("background") is not None:  # camera.h:23 is a public member (default 0): the last three floats of ref_camera
+        import struct
+        n = len(cam.buf.raw)
+        cam.buf[n - 12:n] = struct.pack("<3f", *[float(x) for x in params["background"]])
+    return cam
 
 
 class RefScene:

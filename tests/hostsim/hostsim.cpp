@@ -30,6 +30,7 @@ struct ArrayStack {
     void pop_if(bool c) { if (c && sp > 0) sp--; }
 };
 struct HostCounters {
+    static constexpr bool sphere_slots = true;
     uint64_t nodes = 0, tris = 0, spheres = 0, rays = 0, refolds = 0;
     void node() { nodes++; }
     void tri() { tris++; }
@@ -40,15 +41,10 @@ struct HostCounters {
 };
 SceneView host_view(const crt_scene *s, std::vector<Sphere> &spheres)
 {
-    spheres.resize(s->spheres.size());
-    for (size_t k = 0; k < s->spheres.size(); k++) {
-        Sphere &o = spheres[k];
-        o.cx = s->spheres[k].center.x; o.cy = s->spheres[k].center.y; o.cz = s->spheres[k].center.z; o.radius = s->spheres[k].radius;
-        o.id = (int)(s->tris.size() + k); o.rank = (int)s->rank[s->tris.size() + k]; o.mat = s->spheres[k].material; o.pad = 0;
-    }
+    spheres = s->flat_spheres;
     SceneView v{};
     v.nodes = s->bvh.nodes.data(); v.tris = s->bvh.tris.data(); v.spheres = spheres.data(); v.shades = s->shades.data();
-    v.root_ref = s->bvh.root_ref; v.nnodes = (uint32_t)(s->bvh.nodes.size() / 4); v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size();
+    v.root_ref = s->bvh.root_ref; v.nnodes = (uint32_t)(s->bvh.nodes.size() / 4); v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size(); v.sphere_slots = 1;
     v.root_min = s->bvh.root_box.mn; v.root_max = s->bvh.root_box.mx;
     return v;
 }

@@ -27,9 +27,9 @@ def gpu_scenes(capi, scenes):
     return get
 
 
-def _compare(oracle, scenes, gpu_scenes, name, width, height, spp, **kw):
+def _compare(oracle, scenes, gpu_scenes, name, width, height, spp, camera=None, **kw):
     desc, s = gpu_scenes(name)
-    params, cam = scenes.make_camera(width)
+    params, cam = scenes.make_camera(width, **(camera or {}))
     rgb, ids, st = s.render(cam, width, height, spp, want_ids=True, **kw)
     rs = oracle.RefScene(desc)
     okw = {k: v for k, v in kw.items() if k in ("max_depth", "seed", "sample_offset", "ids_sample")}
@@ -242,3 +242,17 @@ def test_sample_chunks_match_chunked_sum_of_oracle(oracle, scenes, gpu_scenes):
     parts = [s.render(cam, width, height, spp, tile_rank=r, tile_ranks=3, flags=capi.OUT_COMPACT, sample_chunks=n)[0] for r in range(3)]
     full = helpers.untile_numpy(np.concatenate(parts), width, height, 3)
     assert np.array_equal(full.reshape(expect.shape), expect)
+
+
+def test_sphere_scene_on_gpu(oracle, scenes, gpu_scenes, monkeypatch):
+    """Row N3 (scene.h:53-90): 488 spheres (487 of them sphere slots of the BVH), Lambertian / Metal / Dielectric, both
+    kernels, whole pixels and sample chunks."""
+    rgb, ids, st, _ = _compare(oracle, scenes, gpu_scenes, "random_spheres", 320, 180, 4, camera=scenes.SPHERES_CAMERA)
+    _, s = gpu_scenes("random_spheres")
+    _, cam = scenes.make_camera(320, **scenes.SPHERES_CAMERA)
+    rgbc, idsc, stc = s.render(cam, 320, 180, 4, want_ids=True, sample_chunks=4)
+    assert np.array_equal(idsc, ids) and stc.rays == st.rays and np.allclose(rgbc, rgb, rtol=3e-7, atol=1e-7)
+    monkeypatch.setenv("CRT_KERNEL", "1")
+    rgbp, idsp, stp = s.render(cam, 320, 180, 4, want_ids=True)
+    monkeypatch.delenv("CRT_KERNEL", raising=False)
+    assert np.array_equal(rgbp, rgb) and np.array_equal(idsp, ids) and stp.rays == st.rays

@@ -213,3 +213,18 @@ def test_tile_partition_covers_frame_exactly_once(hostsim, scenes):
 def capi_compact(w, h, r):
     from cudaraytracer_amd import capi
     return capi.compact_floats(w, h, r)
+
+
+def test_sphere_scene_with_spheres_in_the_tree(hostsim, oracle, scenes):
+    """Row N3 (scene.h:53-90): 488 spheres, Lambertian / Metal / Dielectric.  487 of them are sphere slots of the BVH (the
+    r = 1000 ground stays in the flat list); ids, image and segment count must still be the oracle's."""
+    desc = scenes.random_spheres()
+    s = hostsim.build(desc)
+    info = s.info()
+    assert info.num_spheres == 488 and info.num_triangles == 0 and info.sphere_bytes == 32 and info.num_nodes > 200
+    width, height, spp = 240, 135, 3
+    params, cam = scenes.make_camera(width, **scenes.SPHERES_CAMERA)
+    fb, ids, _, st = oracle.RefScene(desc).render(oracle.make_camera(params, width), width, height, spp)
+    out, oid, hs = hostsim.render(s, cam, width, height, spp)
+    assert np.array_equal(ids, oid) and np.array_equal(fb, out) and st.rays == hs["rays"]
+    assert len(np.unique(ids)) > 100 and fb.max() > 0.5          # the frame does show the spheres under a sky
