@@ -25,7 +25,11 @@ public:
         crt_render_params p{};
         p.width = m_width; p.height = m_height; p.spp = m_samples_per_pixel; p.max_depth = max_depth; p.seed = seed;
         p.tile_rank = 0; p.tile_ranks = 1; p.sample_chunks = sample_chunks;
-        checkCrtErrors(crt_render((*d_world)->scene, &(*d_camera)->pod, &p, &framebuffer[0].x, nullptr, &last_stats));
+        crt_camera cam = (*d_camera)->pod;
+        cam.background[0] = (*d_camera)->background.x; // Camera::background is a public member (camera.h:23)
+        cam.background[1] = (*d_camera)->background.y;
+        cam.background[2] = (*d_camera)->background.z;
+        checkCrtErrors(crt_render((*d_world)->scene, &cam, &p, &framebuffer[0].x, nullptr, &last_stats));
     }
 
 private:

@@ -41,6 +41,55 @@ public:
         *d_world = world;
     }
 
+    // reference: launch_random_scene_kernel + kernel_create_world (scene.h:53-90, 197-235): ground, 22 x 22 small spheres
+    // (80 % Lambertian(RND*RND), 15 % Metal(0.5(1+RND), 0.5 RND), 5 % Dielectric(1.5)), three r = 1 spheres.  RND is drawn
+    // in the reference's order from a small generator seeded like rand_init (scene.h:183: seed 1984); the reference's
+    // numbers come from curand XORWOW, so the layout is statistically the same scene, not the same spheres.
+    uint64_t random_seed = 1984;
+    void launch_random_scene_kernel(Hittable **d_world)
+    {
+        Hittable *world = new Hittable();
+        uint64_t state = random_seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+        auto RND = [&state]() { // splitmix64 -> (0, 1] on a 2^-24 grid, the range of curand_uniform
+            state += 0x9E3779B97F4A7C15ull;
+            uint64_t z = state;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            z ^= z >> 31;
+            return (float)((uint32_t)(z >> 40) + 1u) * 5.9604644775390625e-08f;
+        };
+        uint32_t n = 0;
+        auto add = [&](float cx, float cy, float cz, float r, int type, float cr, float cg, float cb, float param) {
+            const float rgb[3] = { cr, cg, cb }, c[3] = { cx, cy, cz };
+            uint32_t m = 0;
+            checkCrtErrors(crt_scene_add_material(world->scene, type, rgb, param, UINT32_MAX, &m));
+            checkCrtErrors(crt_scene_add_sphere(world->scene, c, r, m));
+            n++;
+        };
+        add(0.0f, -1000.0f, -1.0f, 1000.0f, CRT_MAT_LAMBERTIAN, 0.5f, 0.5f, 0.5f, 0.0f);
+        for (int a = -11; a < 11; a++)
+            for (int b = -11; b < 11; b++) {
+                const float choose_mat = RND();
+                const float cx = (float)a + RND(), cz = (float)b + RND();
+                if (choose_mat < 0.8f) {
+                    const float r = RND() * RND(), g = RND() * RND(), bl = RND() * RND();
+                    add(cx, 0.2f, cz, 0.2f, CRT_MAT_LAMBERTIAN, r, g, bl, 0.0f);
+                } else if (choose_mat < 0.95f) {
+                    const float r = 0.5f * (1.0f + RND()), g = 0.5f * (1.0f + RND()), bl = 0.5f * (1.0f + RND());
+                    add(cx, 0.2f, cz, 0.2f, CRT_MAT_METAL, r, g, bl, 0.5f * RND());
+                } else {
+                    add(cx, 0.2f, cz, 0.2f, CRT_MAT_DIELECTRIC, 1.0f, 1.0f, 1.0f, 1.5f);
+                }
+            }
+        add(0.0f, 1.0f, 0.0f, 1.0f, CRT_MAT_DIELECTRIC, 1.0f, 1.0f, 1.0f, 1.5f);
+        add(-4.0f, 1.0f, 0.0f, 1.0f, CRT_MAT_LAMBERTIAN, 0.4f, 0.2f, 0.1f, 0.0f);
+        add(4.0f, 1.0f, 0.0f, 1.0f, CRT_MAT_METAL, 0.7f, 0.6f, 0.5f, 0.0f);
+        printf("- Scene Created with %u objects\n", n);
+        checkCrtErrors(crt_scene_commit(world->scene, device));
+        printf("- BVH constructed\n"); // bvh.h:184
+        *d_world = world;
+    }
+
 private:
     std::vector<std::string> model_paths;
 };

@@ -19,17 +19,25 @@ int main(int argc, char **argv)
 
     std::vector<vec3> framebuffer((size_t)IMAGE_WIDTH * IMAGE_HEIGHT);
 
+    // "spheres" instead of a model path: the reference's sphere scene (launch_random_scene_kernel, scene.h:197-235) seen
+    // from the Camera class's own defaults (camera.h:13-15) under a sky-coloured background
+    const bool spheres = model == "spheres";
     // init_camera (kernel.cu:30-42)
     vec3 look_from(8.f, 5.f, -6.0f), look_at(-4, 0, 4), vup(0, 1, 0);
+    if (spheres) { look_from = vec3(13.0f, 2.0f, 3.0f); look_at = vec3(0, 0, 0); }
     const float focus_distance = std::sqrt(look_from.x * look_from.x + look_from.y * look_from.y + look_from.z * look_from.z);
-    Camera *camera = new Camera(IMAGE_WIDTH, look_from, look_at, vup, 25.0f, ASPECT_RATIO, 0.6f, focus_distance);
+    Camera *camera = new Camera(IMAGE_WIDTH, look_from, look_at, vup, spheres ? 20.0f : 25.0f, ASPECT_RATIO, 0.6f, focus_distance);
+    if (spheres) camera->background = vec3(0.7f, 0.8f, 1.0f);
     Camera **d_camera = &camera;
 
     Hittable *world = nullptr;
     Hittable **d_world = &world;
     Scene scene;
-    scene.load_models({ model });
-    scene.launch_triangles_scene(d_world);
+    if (spheres) scene.launch_random_scene_kernel(d_world);
+    else {
+        scene.load_models({ model });
+        scene.launch_triangles_scene(d_world);
+    }
     std::clog << "- Scene Created\n";
 
     Renderer renderer(IMAGE_WIDTH, IMAGE_HEIGHT, tx, ty, spp);

@@ -45,3 +45,18 @@ def test_reference_style_driver_matches_oracle(oracle, scenes, tmp_path):
     assert np.array_equal(img, want)
     from tests.test_output import decode_png
     assert np.array_equal(decode_png(str(tmp_path / "output.png")), want)   # export_framebuffer_to_png (utility.h:122-145)
+
+
+@pytest.mark.gpu
+def test_reference_style_driver_sphere_scene(tmp_path):
+    """launch_random_scene_kernel (scene.h:197-235) through the C++ surface: 488 spheres, PNG out.  The C++ generator's
+    numbers are its own, so the check is on the frame's content, not against the oracle (tests/test_gpu.py does that for
+    the python-described scene)."""
+    from tests.test_output import decode_png
+    r = subprocess.run([DEMO, "spheres", "320", "180", "8"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Scene Created with 488 objects" in r.stdout
+    img = decode_png(str(tmp_path / "output.png"))
+    assert img.shape == (180, 320, 3)
+    sky = img[:20].reshape(-1, 3).mean(axis=0)
+    assert sky[2] > sky[0] > 150 and img[100:].std() > 20      # blue-ish sky on top, structure below
