@@ -272,30 +272,32 @@ CRT_HD bool scatters(int type) { return type == MAT_LAMBERTIAN || type == MAT_ME
 // material.h:10-12, 109-111
 CRT_HD f3 emitted(int type, f3 colour) { return type == MAT_DIFFUSE_LIGHT ? colour : mk3(0.0f, 0.0f, 0.0f); }
 
-// camera.h:88-98 get_ray + 111-119.  Philox stage 0: block 0 = (square.x, square.y, disk0.x, disk0.y), block k>=1
-// = disk draws 2k-1 and 2k; utility.h:100-109 makes up to 10 rejection rounds and returns the 11th unconditionally.
+// (0,1] on a 2^-16 grid from the low half of x: the camera stage's uniforms, two per Philox word (low half first).
+CRT_HD float u01_16(uint32_t x) { return (float)((x & 0xFFFFu) + 1u) * 1.52587890625e-05f; }
+
+// camera.h:88-98 get_ray + 111-119.  Philox stage 0, 16-bit uniforms: block 0 = word 0 (square.x, square.y), words 1..3 =
+// disk draws 0..2; block 1 = draws 3..6; block 2 = draws 7..10.  utility.h:100-109 makes up to 10 rejection rounds and
+// returns the 11th draw unconditionally.  A second block is needed by 0.9 % of the rays (0.2146^3).
 // `r` = Philox block 0 of stage 0 (the caller may have evaluated it together with other lanes' scatter blocks).
 CRT_HD void camera_ray_from(const CameraPOD &cam, uint32_t i, uint32_t j, uint32_t pixel, uint32_t sample, uint32_t k0, uint32_t k1, u4 r,
                             f3 &o, f3 &d)
 {
-    const float ox = fma1(u01(r.x), 0.5f - -0.5f, -0.5f);
-    const float oy = fma1(u01(r.y), 0.5f - -0.5f, -0.5f);
+    const float ox = fma1(u01_16(r.x), 0.5f - -0.5f, -0.5f);
+    const float oy = fma1(u01_16(r.x >> 16), 0.5f - -0.5f, -0.5f);
     const f3 pixel_center = axpy(oy + (float)j, cam.pdv, axpy(ox + (float)i, cam.pdu, cam.pixel00));
     f3 origin = cam.center;
     if (!(cam.defocus_angle <= 0.0f)) {
-        float px = fma1(u01(r.z), 1.0f - -1.0f, -1.0f);
-        float py = fma1(u01(r.w), 1.0f - -1.0f, -1.0f);
-        uint32_t draw = 0, block = 0;
+        uint32_t w = r.y; // draw k lives in word 1 + k of the stage's stream
+        float px = fma1(u01_16(w), 1.0f - -1.0f, -1.0f);
+        float py = fma1(u01_16(w >> 16), 1.0f - -1.0f, -1.0f);
+        uint32_t draw = 0;
         // draws 0..9 are tested; draw 10 is taken as is
         while (draw < 10 && !(__builtin_sqrtf(fma1(0.0f, 0.0f, fma1(py, py, px * px))) < 1.0f)) {
             draw++;
-            if (draw & 1u) {
-                block++;
-                r = philox4x32_10(pixel, sample, 0u, block, k0, k1);
-                px = fma1(u01(r.x), 2.0f, -1.0f); py = fma1(u01(r.y), 2.0f, -1.0f);
-            } else {
-                px = fma1(u01(r.z), 2.0f, -1.0f); py = fma1(u01(r.w), 2.0f, -1.0f);
-            }
+            const uint32_t word = draw + 1u;
+            if ((word & 3u) == 0u) r = philox4x32_10(pixel, sample, 0u, word >> 2, k0, k1);
+            w = (word & 2u) ? ((word & 1u) ? r.w : r.z) : ((word & 1u) ? r.y : r.x);
+            px = fma1(u01_16(w), 2.0f, -1.0f); py = fma1(u01_16(w >> 16), 2.0f, -1.0f);
         }
         origin = axpy(py, cam.disk_v, axpy(px, cam.disk_u, cam.center));
     }
@@ -306,32 +308,6 @@ CRT_HD void camera_ray(const CameraPOD &cam, uint32_t i, uint32_t j, uint32_t pi
                        f3 &o, f3 &d)
 {
     camera_ray_from(cam, i, j, pixel, sample, k0, k1, philox4x32_10(pixel, sample, 0u, 0u, k0, k1), o, d);
-}
-
-// The same get_ray cut at Philox block boundaries, for the kernel's scheduler: `block` 0 computes the pixel point
-// (returned in pixel_center) and tests disk draw 0; block k >= 1 tests draws 2k-1 and 2k (draw 10 is taken as is).
-// Returns true when the ray is complete (o, d written); false: call again with the next block.
-CRT_HD bool camera_ray_step(const CameraPOD &cam, uint32_t i, uint32_t j, uint32_t block, u4 r, f3 &pixel_center, f3 &o, f3 &d)
-{
-    bool done = false;
-    float px = 0.0f, py = 0.0f;
-    if (block == 0) {
-        const float ox = fma1(u01(r.x), 0.5f - -0.5f, -0.5f);
-        const float oy = fma1(u01(r.y), 0.5f - -0.5f, -0.5f);
-        pixel_center = axpy(oy + (float)j, cam.pdv, axpy(ox + (float)i, cam.pdu, cam.pixel00));
-        if (cam.defocus_angle <= 0.0f) { o = cam.center; d = pixel_center - cam.center; return true; }
-    } else {
-        px = fma1(u01(r.x), 2.0f, -1.0f); py = fma1(u01(r.y), 2.0f, -1.0f); // draw 2*block-1 <= 9: always tested
-        done = __builtin_sqrtf(fma1(0.0f, 0.0f, fma1(py, py, px * px))) < 1.0f;
-    }
-    if (!done) {
-        px = fma1(u01(r.z), 2.0f, -1.0f); py = fma1(u01(r.w), 2.0f, -1.0f); // draw 2*block
-        done = 2u * block >= 10u || __builtin_sqrtf(fma1(0.0f, 0.0f, fma1(py, py, px * px))) < 1.0f;
-    }
-    if (!done) return false;
-    o = axpy(py, cam.disk_v, axpy(px, cam.disk_u, cam.center));
-    d = pixel_center - o;
-    return true;
 }
 
 } // namespace crt

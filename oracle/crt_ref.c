@@ -156,6 +156,24 @@ static float rng_uniform(rng_t *g)
 }
 /* utility.h:71-73 random_float: u*(max-min)+min, one fma */
 static inline float random_float(rng_t *g, float mn, float mx) { return fmaf(rng_uniform(g), mx - mn, mn); }
+/* Camera stage (stage 0): uniforms on a 2^-16 grid, two per Philox word (low half first), so that one block serves the
+ * pixel jitter and three defocus-disk draws and the whole rejection loop (<= 11 draws, utility.h:100-109) fits blocks 0..2.
+ * Same range (0,1] as curand_uniform; 2^-16 of a pixel / of the lens radius is far below anything visible. */
+float ref_u01_16(uint32_t h) { return (float)((h & 0xFFFFu) + 1u) * 1.52587890625e-05f; }
+typedef struct { rng_t g; uint32_t word; int half; } rng16_t;
+static float rng16_uniform(rng16_t *h)
+{
+    if (h->half == 0) { /* next word of the stage's stream */
+        if (h->g.have == 0) { ref_philox4x32_10(h->g.ctr, h->g.key, h->g.buf); h->g.ctr[3]++; h->g.have = 4; }
+        h->word = h->g.buf[4 - h->g.have];
+        h->g.have--;
+        h->half = 1;
+        return ref_u01_16(h->word);
+    }
+    h->half = 0;
+    return ref_u01_16(h->word >> 16);
+}
+static inline float random_float16(rng16_t *h, float mn, float mx) { return fmaf(rng16_uniform(h), mx - mn, mn); }
 
 /* ------------------------------------------------------------------------------------------ */
 /* sin/cos on (0, 2*pi] -- stands in for sinf/cosf at utility.h:93-95 (see header)             */
@@ -202,16 +220,16 @@ static v3 random_unit_vector(rng_t *g)
 }
 /* utility.h:100-109 random_in_unit_disk: <=10 rejection rounds then an unconditional 11th draw.
  * draw order inside vec3(random, random, 0): x first, then y. */
-static v3 random_in_unit_disk(rng_t *g)
+static v3 random_in_unit_disk(rng16_t *g)
 {
     for (int i = 0; i < 10; i++) {
-        float px = random_float(g, -1.0f, 1.0f);
-        float py = random_float(g, -1.0f, 1.0f);
+        float px = random_float16(g, -1.0f, 1.0f);
+        float py = random_float16(g, -1.0f, 1.0f);
         v3 p = V(px, py, 0.0f);
         if (vlength(p) < 1.0f) return p;
     }
-    float px = random_float(g, -1.0f, 1.0f);
-    float py = random_float(g, -1.0f, 1.0f);
+    float px = random_float16(g, -1.0f, 1.0f);
+    float py = random_float16(g, -1.0f, 1.0f);
     return V(px, py, 0.0f);
 }
 /* utility.h:111-113 reflect: v - 2*dot(v,n)*n */
@@ -747,10 +765,12 @@ void ref_camera_init(ref_camera *c, uint32_t width, const float from[3], const f
 }
 
 /* camera.h:88-98 get_ray; sample_square draws x then y (camera.h:111-113) */
-static ray_t camera_get_ray(const ref_camera *c, float x, float y, rng_t *g)
+static ray_t camera_get_ray(const ref_camera *c, float x, float y, rng_t *g32)
 {
-    float ox = random_float(g, -0.5f, 0.5f);
-    float oy = random_float(g, -0.5f, 0.5f);
+    rng16_t h; h.g = *g32; h.word = 0; h.half = 0;
+    rng16_t *g = &h;
+    float ox = random_float16(g, -0.5f, 0.5f);
+    float oy = random_float16(g, -0.5f, 0.5f);
     v3 pixel_center = vfma(oy + y, c->pdv, vfma(ox + x, c->pdh, c->pixel00));
     v3 origin = c->center;
     if (!(c->defocus_angle <= 0.0f)) { /* camera.h:115-119 */

@@ -69,6 +69,41 @@ def test_camera_ray_goes_through_focus_plane(oracle):
     assert not np.array_equal(o, o3)
 
 
+def test_camera_stage_stream_layout(oracle):
+    """Stage 0 of the Philox stream: 16-bit uniforms, two per word, low half first; word 0 = square offsets, word 1 + k =
+    defocus-disk draw k.  The ray is recomputed here from raw Philox words and the camera record."""
+    W = 400
+    cam = oracle.RefCamera(W, (8, 5, -6), (-4, 0, 4), (0, 1, 0), 25.0, 16 / 9, 0.6, math.sqrt(125.0))
+    f = np.frombuffer(cam.buf.raw, dtype=np.float32)
+    center, pixel00, pdu, pdv = f[4:7], f[7:10], f[10:13], f[13:16]
+    disk_u, disk_v = f[25:28], f[28:31]
+    f32 = np.float32
+
+    def u16(h):
+        return f32((h & 0xFFFF) + 1) * f32(2.0 ** -16)
+
+    def fma(a, b, c):  # exact in double for these magnitudes, rounded once
+        return f32(np.float64(a) * np.float64(b) + np.float64(c))
+
+    needed_second_block = 0
+    for (i, j, sample) in [(200, 112, 0), (0, 0, 5), (399, 224, 63), (17, 93, 2), (250, 10, 7), (3, 200, 1), (123, 45, 11), (77, 77, 9)]:
+        pixel = j * W + i
+        words = []
+        for block in range(3):
+            words += oracle.philox([pixel, sample, 0, block], [1984, 0])
+        ox, oy = fma(u16(words[0]), f32(1.0), f32(-0.5)), fma(u16(words[0] >> 16), f32(1.0), f32(-0.5))
+        for k in range(11):
+            px, py = fma(u16(words[1 + k]), f32(2.0), f32(-1.0)), fma(u16(words[1 + k] >> 16), f32(2.0), f32(-1.0))
+            if k == 10 or np.sqrt(fma(py, py, f32(px * px))) < 1.0:
+                break
+        needed_second_block += k >= 3
+        o, d = cam.get_ray(W, i, j, sample, 1984)
+        want_o = np.array([fma(py, disk_v[a], fma(px, disk_u[a], center[a])) for a in range(3)], f32)
+        pc = np.array([fma(f32(oy + f32(j)), pdv[a], fma(f32(ox + f32(i)), pdu[a], pixel00[a])) for a in range(3)], f32)
+        assert np.array_equal(o, want_o) and np.array_equal(d, (pc - want_o).astype(f32))
+    assert needed_second_block <= 1
+
+
 def test_slab_test_ignores_interval_and_handles_zero_direction(oracle):
     # aabb.h:72-92
     assert oracle.slab_test((0, 0, 0), (1, 1, 1), (-1, 0.5, 0.5), (1, 0, 0))        # inf * finite slabs pass
