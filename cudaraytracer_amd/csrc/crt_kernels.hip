@@ -134,7 +134,7 @@ enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
 #define CRT_WORK_STRIPES 64u // block counters: an atomic on ONE address costs the device ~5 ns, and every wave waits its turn
 #endif
 #ifndef CRT_NODE_STEPS_PER_VOTE
-#define CRT_NODE_STEPS_PER_VOTE 3
+#define CRT_NODE_STEPS_PER_VOTE 2
 #endif
 #ifndef CRT_WAVES_PER_EU
 #define CRT_WAVES_PER_EU 5 // 512 VGPRs / 5 waves -> 96 registers per lane; the few spills this forces sit on the rare tie path
