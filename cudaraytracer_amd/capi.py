@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("CRT_LIB") or os.path.join(_HERE, "libcrt_hip.so")
 CRT_OK, CRT_ERR_INVALID, CRT_ERR_IO, CRT_ERR_HIP, CRT_ERR_LIMIT, CRT_ERR_NO_DEVICE = range(6)
 TEX_SOLID, TEX_CHECKER = 0, 1
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIFFUSE_LIGHT, MAT_DIELECTRIC = 0, 1, 2, 3
+BUILD_GPU_LBVH = 1
 OUT_ACCUM, OUT_COMPACT, COUNT_WORK = 1, 2, 4
 DEVICE_NONE = -1
 NO_TEXTURE = 0xFFFFFFFF
@@ -48,12 +49,12 @@ class SceneInfo(C.Structure):  # crt_scene_info
     _fields_ = [("num_triangles", C.c_uint32), ("num_spheres", C.c_uint32), ("num_materials", C.c_uint32), ("num_textures", C.c_uint32),
                 ("num_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("max_leaf_size", C.c_uint32), ("device", C.c_uint32),
                 ("node_bytes", C.c_uint64), ("triangle_bytes", C.c_uint64), ("sphere_bytes", C.c_uint64),
-                ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3)]
+                ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3), ("builder", C.c_uint32), ("build_ms", C.c_float)]
 
 
 # every symbol include/crt.h declares (tests check that the library exports exactly these)
 SYMBOLS = ["crt_last_error", "crt_version", "crt_load_obj", "crt_free", "crt_scene_create", "crt_scene_destroy", "crt_scene_add_texture",
-           "crt_scene_add_material", "crt_scene_add_mesh", "crt_scene_add_sphere", "crt_scene_commit", "crt_scene_get_info",
+           "crt_scene_add_material", "crt_scene_add_mesh", "crt_scene_add_sphere", "crt_scene_commit", "crt_scene_commit_ex", "crt_scene_get_info",
            "crt_scene_get_ranks", "crt_camera_init", "crt_render", "crt_compact_floats", "crt_untile", "crt_finalize", "crt_quantize_rgb8", "crt_write_png"]
 
 _lib = None
@@ -86,6 +87,7 @@ def bind(L):
     L.crt_scene_add_mesh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
     L.crt_scene_add_sphere.argtypes = [C.c_void_p, f3, C.c_float, C.c_uint32]
     L.crt_scene_commit.argtypes = [C.c_void_p, C.c_int]
+    L.crt_scene_commit_ex.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
     L.crt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
     L.crt_scene_get_ranks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.crt_camera_init.argtypes = [C.POINTER(Camera), C.c_uint32, f3, f3, f3, C.c_float, C.c_float, C.c_float, C.c_float]
@@ -168,8 +170,11 @@ class Scene:
     def add_sphere(self, center, radius, material):
         _check(self._L.crt_scene_add_sphere(self._h, _f3(center), radius, material), self._L)
 
-    def commit(self, device=0):
-        _check(self._L.crt_scene_commit(self._h, device), self._L)
+    def commit(self, device=0, flags=None):
+        if flags is None:
+            _check(self._L.crt_scene_commit(self._h, device), self._L)
+        else:
+            _check(self._L.crt_scene_commit_ex(self._h, device, flags), self._L)
 
     def info(self):
         info = SceneInfo()

@@ -17,6 +17,8 @@
 
 #include "crt_bvh.h"
 #include "crt_kernels.h"
+#include "crt_lbvh.h"
+#include <chrono>
 
 using namespace crt;
 
@@ -145,6 +147,7 @@ struct crt_scene {
     std::vector<uint32_t> rank;
     FlatBvh bvh;
     std::vector<Shade> shades; // materials joined with their textures (device record)
+    uint32_t builder = 0; float build_ms = 0.0f;
     std::vector<Sphere> flat_spheres; // the spheres that are tested before the walk (the others are slots of the tree)
     void *d_nodes = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_shades = nullptr;
     unsigned long long *d_counters = nullptr;
@@ -267,20 +270,84 @@ static int upload(void **dst, const std::vector<T> &v)
     return CRT_OK;
 }
 
+// GPU builder (crt_lbvh.hip): ranks + LBVH on the device.  Returns false (with everything untouched) when the scene or the
+// resulting tree does not qualify, so that the caller falls back to the host path.
+static bool commit_gpu_lbvh(crt_scene *s, int device, uint32_t max_leaf)
+{
+    if (device < 0 || s->tris.empty() || s->spheres.size() > 8 || s->tris.size() >= (1u << 28)) return false;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev || hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const size_t n = s->tris.size();
+    std::vector<float> tri9(n * 9);
+    std::vector<int> mat(n);
+    for (size_t i = 0; i < n; i++) {
+        const HostTriangle &t = s->tris[i];
+        float *v = &tri9[9 * i];
+        v[0] = t.a.x; v[1] = t.a.y; v[2] = t.a.z; v[3] = t.b.x; v[4] = t.b.y; v[5] = t.b.z; v[6] = t.c.x; v[7] = t.c.y; v[8] = t.c.z;
+        mat[i] = t.material;
+    }
+    std::vector<LbvhSphereInput> sph(s->spheres.size());
+    Box su{};
+    for (size_t k = 0; k < s->spheres.size(); k++) {
+        sph[k].refbox = reference_sphere_box(s->spheres[k]);
+        if (k == 0) su = sph[k].refbox;
+        else { // interval.h:11-14 per axis
+            const Box &b = sph[k].refbox;
+            su.mn.x = su.mn.x <= b.mn.x ? su.mn.x : b.mn.x; su.mx.x = su.mx.x >= b.mx.x ? su.mx.x : b.mx.x;
+            su.mn.y = su.mn.y <= b.mn.y ? su.mn.y : b.mn.y; su.mx.y = su.mx.y >= b.mx.y ? su.mx.y : b.mx.y;
+            su.mn.z = su.mn.z <= b.mn.z ? su.mn.z : b.mn.z; su.mx.z = su.mx.z >= b.mx.z ? su.mx.z : b.mx.z;
+        }
+    }
+    LbvhOutput out;
+    if (lbvh_build(tri9.data(), mat.data(), (uint32_t)n, su, !sph.empty(), sph.data(), (uint32_t)sph.size(), max_leaf, out, nullptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (out.depth > CRT_STACK_DEPTH) return false; // long runs of equal codes: the host builder bounds the depth
+    // ranks: triangles from the device; a sphere follows every triangle with a code <= its own (stable sort, triangles
+    // first in the reference's list) and the spheres that sort before it
+    s->rank.assign(n + s->spheres.size(), 0);
+    std::copy(out.rank_of_tri.begin(), out.rank_of_tri.end(), s->rank.begin());
+    for (size_t k = 0; k < s->spheres.size(); k++) {
+        const uint32_t ck = out.sphere_codes.code[k];
+        uint32_t r = (uint32_t)(std::upper_bound(out.sorted_codes.begin(), out.sorted_codes.end(), ck) - out.sorted_codes.begin());
+        for (size_t j = 0; j < s->spheres.size(); j++) r += (out.sphere_codes.code[j] < ck || (out.sphere_codes.code[j] == ck && j < k)) ? 1u : 0u;
+        s->rank[n + k] = r;
+    }
+    s->bvh = FlatBvh();
+    s->bvh.nodes.swap(out.nodes);
+    s->bvh.tris.swap(out.slots);
+    s->bvh.root_ref = out.root_ref; s->bvh.root_box = out.root_box; s->bvh.depth = out.depth; s->bvh.max_leaf = max_leaf;
+    s->builder = 1; s->build_ms = out.build_ms;
+    return true;
+}
+
 extern "C" int crt_scene_commit(crt_scene *s, int device)
+{
+    const char *b = getenv("CRT_BUILDER");
+    return crt_scene_commit_ex(s, device, (b && strcmp(b, "lbvh") == 0) ? (uint32_t)CRT_BUILD_GPU_LBVH : 0u);
+}
+
+extern "C" int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags)
 {
     if (!s) return fail(CRT_ERR_INVALID, "crt_scene_commit: null scene");
     if (s->tris.empty() && s->spheres.empty()) return fail(CRT_ERR_INVALID, "crt_scene_commit: empty scene");
     s->release_device();
     s->prepared = false;
 
-    // reference order: all triangles, then all spheres (scene.h:161-165)
-    std::vector<Box> boxes;
-    boxes.reserve(s->tris.size() + s->spheres.size());
-    for (const HostTriangle &t : s->tris) boxes.push_back(reference_triangle_box(t));
-    for (const HostSphere &sp : s->spheres) boxes.push_back(reference_sphere_box(sp));
-    Box scene_box;
-    reference_ranks(boxes, s->rank, scene_box);
+    const uint32_t max_leaf = (uint32_t)get_env_int("CRT_MAX_LEAF", 2);
+    s->builder = 0; s->build_ms = 0.0f;
+    const bool gpu_built = (flags & CRT_BUILD_GPU_LBVH) && commit_gpu_lbvh(s, device, std::min(std::max(max_leaf, 1u), 8u));
+    const auto host_t0 = std::chrono::steady_clock::now();
+    if (!gpu_built) {
+        // reference order: all triangles, then all spheres (scene.h:161-165)
+        std::vector<Box> boxes;
+        boxes.reserve(s->tris.size() + s->spheres.size());
+        for (const HostTriangle &t : s->tris) boxes.push_back(reference_triangle_box(t));
+        for (const HostSphere &sp : s->spheres) boxes.push_back(reference_sphere_box(sp));
+        Box scene_box;
+        reference_ranks(boxes, s->rank, scene_box);
+    }
 
     // Where the spheres go.  A few spheres (the reference's triangle scenes have two, scene.h:164-165) stay a flat list
     // tested before the walk, so the r = 1000 ground never inflates the tree (F10).  A scene made of spheres
@@ -310,8 +377,10 @@ extern "C" int crt_scene_commit(crt_scene *s, int device)
     if (flat.size() > 4096) return fail(CRT_ERR_LIMIT, "crt_scene_commit: more than 4096 spheres outside the tree");
     const std::vector<Sphere> &spheres = flat;
 
-    const uint32_t max_leaf = (uint32_t)get_env_int("CRT_MAX_LEAF", 2);
-    build_bvh(s->tris, s->rank, tree_spheres, max_leaf, s->bvh);
+    if (!gpu_built) {
+        build_bvh(s->tris, s->rank, tree_spheres, max_leaf, s->bvh);
+        s->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
+    }
     if (s->bvh.depth > CRT_STACK_DEPTH) return fail(CRT_ERR_LIMIT, "crt_scene_commit: BVH deeper than the traversal stack");
 
     s->shades.assign(s->mats.size(), Shade{});
@@ -373,6 +442,7 @@ extern "C" int crt_scene_get_info(const crt_scene *s, crt_scene_info *info)
     info->node_bytes = s->bvh.nodes.size() * sizeof(q4); info->triangle_bytes = s->bvh.tris.size() * sizeof(q4);
     info->sphere_bytes = s->flat_spheres.size() * sizeof(Sphere);
     info->bounds_min[0] = s->bvh.root_box.mn.x; info->bounds_min[1] = s->bvh.root_box.mn.y; info->bounds_min[2] = s->bvh.root_box.mn.z;
+    info->builder = s->builder; info->build_ms = s->build_ms;
     info->bounds_max[0] = s->bvh.root_box.mx.x; info->bounds_max[1] = s->bvh.root_box.mx.y; info->bounds_max[2] = s->bvh.root_box.mx.z;
     return CRT_OK;
 }

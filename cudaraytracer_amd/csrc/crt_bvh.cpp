@@ -1,6 +1,7 @@
 // crt_bvh.cpp -- see crt_bvh.h.  Host code; float arithmetic that feeds ranks is written exactly as the
 // reference evaluates it (no contraction: this file is built with -ffp-contract=off).
 #include "crt_bvh.h"
+#include "crt_lbvh.h"
 
 #include <algorithm>
 #include <cmath>
@@ -64,6 +65,14 @@ static inline uint32_t morton_3d(f3 p)
     const float y = fminf(fmaxf(p.y * 1024.0f, 0.0f), 1023.0f);
     const float z = fminf(fmaxf(p.z * 1024.0f, 0.0f), 1023.0f);
     return expand_bits((uint32_t)x) * 4 + expand_bits((uint32_t)y) * 2 + expand_bits((uint32_t)z);
+}
+
+uint32_t lbvh_host_morton(const Box &refbox, const Box &scene)
+{
+    const f3 extent = scene.mx - scene.mn;
+    const f3 centroid = (refbox.mn + refbox.mx) * 0.5f; // aabb.h:38-40
+    const f3 rel = centroid - scene.mn;
+    return morton_3d(mk3(rel.x / extent.x, rel.y / extent.y, rel.z / extent.z));
 }
 
 void reference_ranks(const std::vector<Box> &boxes, std::vector<uint32_t> &rank, Box &scene_box)

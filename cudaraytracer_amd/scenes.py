@@ -147,8 +147,8 @@ def random_spheres(seed=1984):
 SPHERES_CAMERA = dict(lookfrom=(13.0, 2.0, 3.0), lookat=(0.0, 0.0, 0.0), vfov=20.0, background=(0.7, 0.8, 1.0))
 
 
-def build(desc, device=0):
-    """Description -> committed capi.Scene."""
+def build(desc, device=0, flags=None):
+    """Description -> committed capi.Scene (flags: capi.BUILD_GPU_LBVH for the device-side builder)."""
     s = capi.Scene()
     for t in desc["textures"]:
         s.add_texture(t["type"], t["a"], t.get("b"), t.get("scale", 1.0))
@@ -159,7 +159,7 @@ def build(desc, device=0):
         s.add_mesh(me["vertices"], me["indices"], me["material"])
     for sp in desc["spheres"]:
         s.add_sphere(sp["center"], sp["radius"], sp["material"])
-    s.commit(device)
+    s.commit(device, flags)
     return s
 
 

@@ -71,6 +71,14 @@ int crt_scene_add_sphere(crt_scene *s, const float center[3], float radius, uint
  * own SAH BVH (64-byte two-child nodes) and uploads everything to HIP device `device`. */
 #define CRT_DEVICE_NONE (-1) /* prepare on the host only (ranks, BVH, crt_scene_get_*); crt_render then fails with CRT_ERR_NO_DEVICE */
 int crt_scene_commit(crt_scene *s, int device);
+/* The same with a choice of builder.  CRT_BUILD_GPU_LBVH (SURVEY "next" row N1; reference: assign_morton_codes +
+ * thrust::sort_by_key + build_bvh<<<1,1>>>, bvh.h:13-185, scene.h:288-307): boxes, Morton codes, the stable radix sort
+ * (= the ranks) and a Karras LBVH over that order are computed on the device in milliseconds; the tree traverses slower
+ * than the host's SAH tree, the rendered result is the same.  Needs a device, triangles and at most 8 spheres; falls
+ * back to the host builder otherwise (crt_scene_info.builder tells).  crt_scene_commit(s, d) = commit_ex(s, d, 0), or
+ * CRT_BUILD_GPU_LBVH when the environment has CRT_BUILDER=lbvh. */
+enum { CRT_BUILD_GPU_LBVH = 1u };
+int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags);
 
 typedef struct crt_scene_info {
     uint32_t num_triangles, num_spheres, num_materials, num_textures;
@@ -80,6 +88,8 @@ typedef struct crt_scene_info {
     uint32_t device;         /* UINT32_MAX when prepared with CRT_DEVICE_NONE */
     uint64_t node_bytes, triangle_bytes, sphere_bytes; /* resident HBM footprint */
     float bounds_min[3], bounds_max[3];                /* triangle BVH root box  */
+    uint32_t builder;        /* 0 = host SAH, 1 = GPU LBVH                                                  */
+    float build_ms;          /* GPU LBVH: hipEvent time of the build kernels and the sort; host SAH: wall time */
 } crt_scene_info;
 int crt_scene_get_info(const crt_scene *s, crt_scene_info *info);
 /* rank[i] = position of primitive i (triangles first, then spheres) in the reference's sorted Morton order

@@ -256,3 +256,38 @@ def test_sphere_scene_on_gpu(oracle, scenes, gpu_scenes, monkeypatch):
     rgbp, idsp, stp = s.render(cam, 320, 180, 4, want_ids=True)
     monkeypatch.delenv("CRT_KERNEL", raising=False)
     assert np.array_equal(rgbp, rgb) and np.array_equal(idsp, ids) and stp.rays == st.rays
+
+
+@pytest.mark.parametrize("name", ["cat", "cats"])
+def test_gpu_lbvh_builder_same_ranks_same_image(oracle, capi, scenes, name):
+    """Row N1: ranks and tree built on the device (crt_lbvh.hip).  The ranks must be the host's (= the oracle's leaf
+    order); the tree is another one, the rendered result may not differ in a single bit."""
+    desc = getattr(scenes, name)()
+    host = scenes.build(desc, 0)
+    gpu = scenes.build(desc, 0, capi.BUILD_GPU_LBVH)
+    ih, ig = host.info(), gpu.info()
+    assert (ih.builder, ig.builder) == (0, 1) and ig.num_triangles == ih.num_triangles and 0 < ig.bvh_depth <= 32
+    assert np.array_equal(host.ranks(), gpu.ranks())
+    assert np.allclose(np.array(ig.bounds_min), np.array(ih.bounds_min)) and np.allclose(np.array(ig.bounds_max), np.array(ih.bounds_max))
+    width, height, spp = 320, 180, 4
+    params, cam = scenes.make_camera(width)
+    rgb_h, ids_h, st_h = host.render(cam, width, height, spp, want_ids=True)
+    rgb_g, ids_g, st_g = gpu.render(cam, width, height, spp, want_ids=True)
+    assert np.array_equal(ids_g, ids_h) and np.array_equal(rgb_g, rgb_h) and st_g.rays == st_h.rays
+    fb, rids, _, rst = oracle.RefScene(desc).render(oracle.make_camera(params, width), width, height, spp)
+    assert np.array_equal(ids_g, rids) and np.array_equal(rgb_g.reshape(fb.shape), fb) and st_g.rays == rst.rays
+
+
+def test_gpu_lbvh_builder_on_the_1m_triangle_scene(capi, scenes):
+    desc = scenes.cat_grid()
+    host = scenes.build(desc, 0)
+    gpu = scenes.build(desc, 0, capi.BUILD_GPU_LBVH)
+    ig = gpu.info()
+    assert ig.builder == 1 and ig.num_triangles == 999912 and ig.bvh_depth <= 32
+    assert np.array_equal(host.ranks(), gpu.ranks())
+    print("build: host SAH %.0f ms, GPU LBVH %.2f ms (depth %d vs %d)" % (host.info().build_ms, ig.build_ms, host.info().bvh_depth, ig.bvh_depth))
+    assert ig.build_ms < 100.0
+    _, cam = scenes.make_camera(480, **scenes.GRID_CAMERA)
+    rgb_h, ids_h, st_h = host.render(cam, 480, 270, 2, want_ids=True)
+    rgb_g, ids_g, st_g = gpu.render(cam, 480, 270, 2, want_ids=True)
+    assert np.array_equal(ids_g, ids_h) and np.array_equal(rgb_g, rgb_h) and st_g.rays == st_h.rays
