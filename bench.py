@@ -141,7 +141,7 @@ def main():
             return frame.render_local(scene, cam, spp, depth, seed, want_stats=want_stats, flags=flags)
         finish = frame.gather
     else:
-        frame = SampleFrame(W, H, spp, world, rank, device)
+        frame = SampleFrame(W, H, spp, world, rank, device, sample_chunks=chunks)
 
         def launch(want_stats=False, flags=0):
             return frame.render_local(scene, cam, depth, seed, want_stats=want_stats)
@@ -187,7 +187,7 @@ def main():
         stw = frame.render_local(scene, cam, spp, depth, seed, want_stats=True, flags=capi.COUNT_WORK)
     else:
         stw = scene.render(cam, W, H, frame.spp_local, max_depth=depth, seed=seed, sample_offset=rank * frame.spp_local,
-                           flags=capi.OUT_ACCUM | capi.COUNT_WORK, out_rgb=frame.accum.data_ptr(), want_stats=True)[2]
+                           flags=capi.OUT_ACCUM | capi.COUNT_WORK, out_rgb=frame.accum.data_ptr(), want_stats=True, sample_chunks=frame.sample_chunks)[2]
     torch.cuda.synchronize()
 
     if rank == 0:
@@ -204,7 +204,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d %dspp depth %d (models/%s + ground + emissive sphere, seed %d)" %
                        (args.workload, W, H, spp, depth, {"cats": "cats.obj", "random_spheres": "no mesh"}.get(builder, "cat.obj"), seed),
-                       "partition": "%s x%d" % (args.mode, world), "sample_chunks": chunks if args.mode == "tile" else 1, "triangles": info.num_triangles, "bvh_nodes": info.num_nodes,
+                       "partition": "%s x%d" % (args.mode, world), "sample_chunks": chunks if args.mode == "tile" else frame.sample_chunks, "triangles": info.num_triangles, "bvh_nodes": info.num_nodes,
                        "rays_per_frame": int(rays_frame), "device_cus": cus},
             "roofline": {"bound": "valu", "achieved": ops / ksec / 1e12, "peak": valu_peak, "unit": "Tlane-op/s",
                          "frac": ops / ksec / 1e12 / valu_peak, "traffic": traffic,

@@ -59,11 +59,14 @@ class TileFrame:
 class SampleFrame:
     """Sample-partitioned frame: render_local() -> reduce() -> self.frame (valid on rank 0)."""
 
-    def __init__(self, width, height, total_spp, world, rank, device, finalize_fn=None):
+    def __init__(self, width, height, total_spp, world, rank, device, finalize_fn=None, sample_chunks=0):
         if total_spp % world:
             raise ValueError("total_spp must be a multiple of the world size")
         self.width, self.height, self.world, self.rank, self.total_spp = width, height, world, rank, total_spp
         self.spp_local = total_spp // world
+        self.sample_chunks = sample_chunks
+        while self.sample_chunks > 1 and self.spp_local % self.sample_chunks:
+            self.sample_chunks //= 2
         self.accum = torch.zeros(height * width * 3, dtype=torch.float32, device=device)
         self.frame = torch.zeros_like(self.accum)
         self.finalize_fn = finalize_fn or _device_finalize
@@ -71,7 +74,8 @@ class SampleFrame:
     def render_local(self, scene, cam, max_depth, seed, want_stats=False):
         stream = torch.cuda.current_stream(self.accum.device).cuda_stream
         return scene.render(cam, self.width, self.height, self.spp_local, max_depth=max_depth, seed=seed, sample_offset=self.rank * self.spp_local,
-                            flags=capi.OUT_ACCUM, out_rgb=self.accum.data_ptr(), want_stats=want_stats, stream=stream)[2]
+                            flags=capi.OUT_ACCUM, out_rgb=self.accum.data_ptr(), want_stats=want_stats, stream=stream,
+                            sample_chunks=self.sample_chunks)[2]
 
     def reduce(self):
         if self.world > 1:
