@@ -45,6 +45,11 @@ class Stats(C.Structure):  # crt_stats
                 ("shaded_hits", C.c_uint64), ("sched", C.c_uint64 * 10), ("kernel_ms", C.c_float), ("reserved", C.c_uint32)]
 
 
+class ObjGroup(C.Structure):  # crt_obj_group
+    _fields_ = [("object", C.c_char * 64), ("material", C.c_char * 64), ("Kd", C.c_float * 3), ("Ke", C.c_float * 3), ("Ns", C.c_float), ("Ni", C.c_float),
+                ("d", C.c_float), ("illum", C.c_int32), ("first_triangle", C.c_uint32), ("num_triangles", C.c_uint32)]
+
+
 class SceneInfo(C.Structure):  # crt_scene_info
     _fields_ = [("num_triangles", C.c_uint32), ("num_spheres", C.c_uint32), ("num_materials", C.c_uint32), ("num_textures", C.c_uint32),
                 ("num_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("max_leaf_size", C.c_uint32), ("device", C.c_uint32),
@@ -53,7 +58,7 @@ class SceneInfo(C.Structure):  # crt_scene_info
 
 
 # every symbol include/crt.h declares (tests check that the library exports exactly these)
-SYMBOLS = ["crt_last_error", "crt_version", "crt_load_obj", "crt_free", "crt_scene_create", "crt_scene_destroy", "crt_scene_add_texture",
+SYMBOLS = ["crt_last_error", "crt_version", "crt_load_obj", "crt_load_obj_ex", "crt_free", "crt_scene_create", "crt_scene_destroy", "crt_scene_add_texture",
            "crt_scene_add_material", "crt_scene_add_mesh", "crt_scene_add_sphere", "crt_scene_commit", "crt_scene_commit_ex", "crt_scene_get_info",
            "crt_scene_get_ranks", "crt_camera_init", "crt_render", "crt_compact_floats", "crt_untile", "crt_finalize", "crt_quantize_rgb8", "crt_write_png"]
 
@@ -77,6 +82,8 @@ def bind(L):
     L.crt_last_error.restype = C.c_char_p
     L.crt_version.restype = C.c_int
     L.crt_load_obj.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32)]
+    L.crt_load_obj_ex.argtypes = [C.c_char_p, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32),
+                                  C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.POINTER(ObjGroup)), C.POINTER(C.c_uint32)]
     L.crt_free.argtypes = [C.c_void_p]
     L.crt_free.restype = None
     L.crt_scene_create.restype = C.c_void_p
@@ -238,3 +245,21 @@ def write_png(path, rgb8):
     rgb8 = np.ascontiguousarray(rgb8, dtype=np.uint8)
     h, w = rgb8.shape[:2]
     _check(lib().crt_write_png(os.fsencode(path), rgb8.ctypes.data, w, h))
+
+
+def load_obj_groups(path):
+    """crt_load_obj_ex -> (vertices [n,6] float32, indices [m,3] uint32, tri_group [m] uint32, groups: list of dicts)."""
+    L = lib()
+    v, i, g, gr = C.POINTER(C.c_float)(), C.POINTER(C.c_uint32)(), C.POINTER(C.c_uint32)(), C.POINTER(ObjGroup)()
+    nv, nt, ng = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    _check(L.crt_load_obj_ex(os.fsencode(path), C.byref(v), C.byref(nv), C.byref(i), C.byref(nt), C.byref(g), C.byref(gr), C.byref(ng)), L)
+    try:
+        verts = np.ctypeslib.as_array(v, shape=(nv.value, 6)).copy()
+        idx = np.ctypeslib.as_array(i, shape=(nt.value, 3)).copy()
+        tg = np.ctypeslib.as_array(g, shape=(nt.value,)).copy()
+        groups = [dict(object=gr[k].object.decode(), material=gr[k].material.decode(), Kd=tuple(gr[k].Kd), Ke=tuple(gr[k].Ke), Ns=gr[k].Ns, Ni=gr[k].Ni,
+                       d=gr[k].d, illum=gr[k].illum, first_triangle=gr[k].first_triangle, num_triangles=gr[k].num_triangles) for k in range(ng.value)]
+    finally:
+        for ptr in (v, i, g, gr):
+            L.crt_free(C.cast(ptr, C.c_void_p))
+    return verts, idx, tg, groups

@@ -14,7 +14,7 @@ public:
 
     Model(const std::string &modelFilePath)
     {
-        if (!LoadModel(modelFilePath, h_vertex, h_indices)) {
+        if (!LoadModel(modelFilePath, h_vertex, h_indices, &groups)) {
             std::cerr << "Failed to load OBJ model!" << std::endl; // model.h:19
             return;
         }
@@ -25,4 +25,5 @@ public:
     }
     std::vector<Vertex> h_vertex;
     std::vector<uint32_t> h_indices;
+    std::vector<crt_obj_group> groups; // parts of the file with their .mtl records (not in the reference)
 };

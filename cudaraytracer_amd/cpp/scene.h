@@ -15,6 +15,9 @@ public:
     // reference: declared at scene.h:25, never defined; here it selects the OBJ files launch_triangles_scene() loads
     void load_models(const std::vector<std::string> &modelPaths) { model_paths = modelPaths; }
     int device = 0;
+    // false (reference, scene.h:147-148): every triangle Lambertian(0.7, 0.3, 0.16).  true (row N4): each part of a model
+    // gets its .mtl material -- DiffuseLight(Ke) when it emits, else Lambertian(Kd).
+    bool materials_from_mtl = false;
 
     void launch_triangles_scene(Hittable **d_world)
     {
@@ -26,8 +29,17 @@ public:
         for (const std::string &path : model_paths) {
             Model model(path);
             if (model.num_triangles == 0) continue;
-            checkCrtErrors(crt_scene_add_mesh(world->scene, &model.d_vertex[0].position.x, sizeof(Vertex) / sizeof(float), model.num_vertices,
-                                              model.d_indices, model.num_triangles, tri_mat));
+            if (materials_from_mtl) {
+                for (const crt_obj_group &g : model.groups) {
+                    const bool emits = g.Ke[0] > 0.0f || g.Ke[1] > 0.0f || g.Ke[2] > 0.0f;
+                    uint32_t m = 0;
+                    checkCrtErrors(crt_scene_add_material(world->scene, emits ? CRT_MAT_DIFFUSE_LIGHT : CRT_MAT_LAMBERTIAN, emits ? g.Ke : g.Kd, 0.0f, UINT32_MAX, &m));
+                    checkCrtErrors(crt_scene_add_mesh(world->scene, &model.d_vertex[0].position.x, sizeof(Vertex) / sizeof(float), model.num_vertices,
+                                                      model.d_indices + 3 * (size_t)g.first_triangle, g.num_triangles, m));
+                }
+            } else
+                checkCrtErrors(crt_scene_add_mesh(world->scene, &model.d_vertex[0].position.x, sizeof(Vertex) / sizeof(float), model.num_vertices,
+                                                  model.d_indices, model.num_triangles, tri_mat));
             num_triangles += model.num_triangles;
         }
         checkCrtErrors(crt_scene_add_material(world->scene, CRT_MAT_LAMBERTIAN, ground_rgb, 0.0f, UINT32_MAX, &ground_mat));

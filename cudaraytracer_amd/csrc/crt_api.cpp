@@ -73,15 +73,57 @@ static bool parse_corner(const char *&p, long nv, long nn, long &vi, long &ni)
     return true;
 }
 
-extern "C" int crt_load_obj(const char *path, float **xyz_nrm, uint32_t *nverts, uint32_t **indices, uint32_t *ntris)
+namespace {
+struct MtlRecord { std::string name; float Kd[3] = { 0.8f, 0.8f, 0.8f }, Ke[3] = { 0, 0, 0 }, Ns = 0.0f, Ni = 1.0f, d = 1.0f; int illum = 1; };
+
+std::string first_word(const char *p)
+{
+    while (*p == ' ' || *p == '\t') p++;
+    const char *e = p;
+    while (*e && *e != '\n' && *e != '\r') e++;
+    while (e > p && (e[-1] == ' ' || e[-1] == '\t')) e--;
+    return std::string(p, e);
+}
+
+void read_mtl(const std::string &path, std::vector<MtlRecord> &out)
+{
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return; // a missing library leaves the defaults (Assimp does the same with a warning)
+    char line[4096];
+    while (fgets(line, sizeof line, f)) {
+        const char *p = line;
+        while (*p == ' ' || *p == '\t') p++;
+        char *e;
+        if (!strncmp(p, "newmtl", 6) && (p[6] == ' ' || p[6] == '\t')) { out.emplace_back(); out.back().name = first_word(p + 7); continue; }
+        if (out.empty()) continue;
+        MtlRecord &m = out.back();
+        if (!strncmp(p, "Kd ", 3)) { p += 3; for (int k = 0; k < 3; k++) { m.Kd[k] = strtof(p, &e); p = e; } }
+        else if (!strncmp(p, "Ke ", 3)) { p += 3; for (int k = 0; k < 3; k++) { m.Ke[k] = strtof(p, &e); p = e; } }
+        else if (!strncmp(p, "Ns ", 3)) m.Ns = strtof(p + 3, &e);
+        else if (!strncmp(p, "Ni ", 3)) m.Ni = strtof(p + 3, &e);
+        else if (!strncmp(p, "d ", 2)) m.d = strtof(p + 2, &e);
+        else if (!strncmp(p, "illum ", 6)) m.illum = (int)strtol(p + 6, &e, 10);
+    }
+    fclose(f);
+}
+} // namespace
+
+extern "C" int crt_load_obj_ex(const char *path, float **xyz_nrm, uint32_t *nverts, uint32_t **indices, uint32_t *ntris, uint32_t **tri_group,
+                               crt_obj_group **groups, uint32_t *ngroups)
 {
     if (!path || !xyz_nrm || !nverts || !indices || !ntris) return fail(CRT_ERR_INVALID, "crt_load_obj: null argument");
+    if ((tri_group || groups || ngroups) && !(tri_group && groups && ngroups)) return fail(CRT_ERR_INVALID, "crt_load_obj_ex: group outputs go together");
     *xyz_nrm = nullptr; *indices = nullptr; *nverts = 0; *ntris = 0;
+    if (tri_group) { *tri_group = nullptr; *groups = nullptr; *ngroups = 0; }
     FILE *f = fopen(path, "rb");
     if (!f) return fail(CRT_ERR_IO, std::string("crt_load_obj: cannot open ") + path);
     std::vector<float> pos, nrm;
     std::vector<float> verts;         // 6 floats per joined vertex
-    std::vector<uint32_t> idx;
+    std::vector<uint32_t> idx, tgroup;
+    std::vector<crt_obj_group> grp;
+    std::vector<MtlRecord> mtl;
+    std::string cur_object, cur_material;
+    bool group_open = false;
     std::map<std::pair<long, long>, uint32_t> joined; // (v, vn) -> vertex, first use order
     std::vector<char> line(1 << 16);
     int rc = CRT_OK;
@@ -96,6 +138,17 @@ extern "C" int crt_load_obj(const char *path, float **xyz_nrm, uint32_t *nverts,
             char *e;
             p += 3;
             for (int k = 0; k < 3; k++) { nrm.push_back(strtof(p, &e)); p = e; }
+        } else if ((p[0] == 'o' || p[0] == 'g') && (p[1] == ' ' || p[1] == '\t')) {
+            cur_object = first_word(p + 2); group_open = false;
+        } else if (!strncmp(p, "usemtl", 6) && (p[6] == ' ' || p[6] == '\t')) {
+            cur_material = first_word(p + 7); group_open = false;
+        } else if (!strncmp(p, "mtllib", 6) && (p[6] == ' ' || p[6] == '\t')) {
+            if (tri_group) {
+                std::string dir(path);
+                const size_t slash = dir.find_last_of('/');
+                dir = slash == std::string::npos ? std::string() : dir.substr(0, slash + 1);
+                read_mtl(dir + first_word(p + 7), mtl);
+            }
         } else if (p[0] == 'f' && (p[1] == ' ' || p[1] == '\t')) {
             p += 2;
             std::vector<uint32_t> corner;
@@ -114,22 +167,59 @@ extern "C" int crt_load_obj(const char *path, float **xyz_nrm, uint32_t *nverts,
                 corner.push_back(it->second);
             }
             if (rc != CRT_OK) break;
+            if (!group_open && corner.size() >= 3) {
+                crt_obj_group g;
+                memset(&g, 0, sizeof g);
+                snprintf(g.object, sizeof g.object, "%s", cur_object.c_str());
+                snprintf(g.material, sizeof g.material, "%s", cur_material.c_str());
+                g.first_triangle = (uint32_t)(idx.size() / 3);
+                grp.push_back(g);
+                group_open = true;
+            }
             for (size_t k = 2; k < corner.size(); k++) { // aiProcess_Triangulate: fan
                 idx.push_back(corner[0]); idx.push_back(corner[k - 1]); idx.push_back(corner[k]);
+                tgroup.push_back((uint32_t)grp.size() - 1);
+                grp.back().num_triangles++;
             }
         }
     }
     fclose(f);
     if (rc != CRT_OK) return rc;
     if (idx.empty()) return fail(CRT_ERR_IO, std::string("crt_load_obj: no faces in ") + path);
+    for (crt_obj_group &g : grp) { // material records (the library may come after the faces in the file)
+        MtlRecord m;
+        for (const MtlRecord &r : mtl) if (r.name == g.material) m = r;
+        for (int k = 0; k < 3; k++) { g.Kd[k] = m.Kd[k]; g.Ke[k] = m.Ke[k]; }
+        g.Ns = m.Ns; g.Ni = m.Ni; g.d = m.d; g.illum = m.illum;
+    }
     *xyz_nrm = (float *)malloc(verts.size() * sizeof(float));
     *indices = (uint32_t *)malloc(idx.size() * sizeof(uint32_t));
-    if (!*xyz_nrm || !*indices) { free(*xyz_nrm); free(*indices); *xyz_nrm = nullptr; *indices = nullptr; return fail(CRT_ERR_LIMIT, "crt_load_obj: out of memory"); }
+    bool ok = *xyz_nrm && *indices;
+    if (tri_group) {
+        *tri_group = (uint32_t *)malloc(tgroup.size() * sizeof(uint32_t));
+        *groups = (crt_obj_group *)malloc(grp.size() * sizeof(crt_obj_group));
+        ok = ok && *tri_group && *groups;
+    }
+    if (!ok) {
+        free(*xyz_nrm); free(*indices); *xyz_nrm = nullptr; *indices = nullptr;
+        if (tri_group) { free(*tri_group); free(*groups); *tri_group = nullptr; *groups = nullptr; }
+        return fail(CRT_ERR_LIMIT, "crt_load_obj: out of memory");
+    }
     memcpy(*xyz_nrm, verts.data(), verts.size() * sizeof(float));
     memcpy(*indices, idx.data(), idx.size() * sizeof(uint32_t));
     *nverts = (uint32_t)(verts.size() / 6);
     *ntris = (uint32_t)(idx.size() / 3);
+    if (tri_group) {
+        memcpy(*tri_group, tgroup.data(), tgroup.size() * sizeof(uint32_t));
+        memcpy(*groups, grp.data(), grp.size() * sizeof(crt_obj_group));
+        *ngroups = (uint32_t)grp.size();
+    }
     return CRT_OK;
+}
+
+extern "C" int crt_load_obj(const char *path, float **xyz_nrm, uint32_t *nverts, uint32_t **indices, uint32_t *ntris)
+{
+    return crt_load_obj_ex(path, xyz_nrm, nverts, indices, ntris, nullptr, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -40,6 +40,21 @@ int crt_version(void);
  *   *indices : ntris * 3 uint32 */
 int crt_load_obj(const char *path, float **xyz_nrm, uint32_t *nverts, uint32_t **indices, uint32_t *ntris);
 void crt_free(void *p);
+/* SURVEY "next" row N4: the same reader, also returning which part of the file every triangle belongs to.  A group is a
+ * run of faces under one `o`/`g` object and one `usemtl` material; its material record comes from the file's `mtllib`
+ * (searched beside the OBJ): Kd, Ke, Ns, Ni, d, illum with the MTL defaults when a statement or the file is missing.
+ * (Assimp splits such a file into several aiMesh; the reference's LoadModel concatenates their indices without the
+ * base-vertex offset, model_loader.h:26-49 -- here indices always refer to the one joined vertex array.)
+ *   *tri_group : ntris uint32, index into *groups;   *groups : ngroups records (malloc'ed, crt_free) */
+typedef struct crt_obj_group {
+    char object[64], material[64];  /* names, truncated, "" when the file has none                                 */
+    float Kd[3], Ke[3];             /* diffuse colour (default 0.8), emission (default 0)                          */
+    float Ns, Ni, d;                /* specular exponent (0), index of refraction (1), dissolve (1)                */
+    int32_t illum;                  /* illumination model (1)                                                      */
+    uint32_t first_triangle, num_triangles; /* triangles of a group are contiguous in file order                  */
+} crt_obj_group;
+int crt_load_obj_ex(const char *path, float **xyz_nrm, uint32_t *nverts, uint32_t **indices, uint32_t *ntris, uint32_t **tri_group,
+                    crt_obj_group **groups, uint32_t *ngroups);
 
 /* ---- scene -------------------------------------------------------------------------------------------- */
 /* reference: class Scene (scene.h:20-51) whose launch_*_scene() writes a device HittableList into

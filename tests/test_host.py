@@ -228,3 +228,27 @@ def test_sphere_scene_with_spheres_in_the_tree(hostsim, oracle, scenes):
     out, oid, hs = hostsim.render(s, cam, width, height, spp)
     assert np.array_equal(ids, oid) and np.array_equal(fb, out) and st.rays == hs["rays"]
     assert len(np.unique(ids)) > 100 and fb.max() > 0.5          # the frame does show the spheres under a sky
+
+
+def test_obj_groups_and_mtl_records(capi, tmp_path):
+    """Row N4 (crt_load_obj_ex): objects / usemtl runs with their .mtl records; indices always refer to the one joined vertex
+    array (the reference concatenates Assimp meshes without the base-vertex offset, model_loader.h:26-49)."""
+    (tmp_path / "two.mtl").write_text(
+        "newmtl red\nKd 0.9 0.1 0.1\nNs 10\n\nnewmtl lamp\nKd 0 0 0\nKe 4 5 6\nillum 2\nNi 1.45\nd 0.5\n")
+    (tmp_path / "two.obj").write_text(
+        "mtllib two.mtl\n"
+        "o floor\nv 0 0 0\nv 1 0 0\nv 1 0 1\nv 0 0 1\nusemtl red\nf 1 2 3 4\n"
+        "o bulb\nv 0 1 0\nv 1 1 0\nv 0 1 1\nusemtl lamp\nf 5 6 7\nusemtl nowhere\nf -3 -2 -1\nf 1 5 6\n")
+    v, i, tg, groups = capi.load_obj_groups(str(tmp_path / "two.obj"))
+    assert v.shape == (7, 6) and i.shape == (5, 3)
+    assert [g["object"] for g in groups] == ["floor", "bulb", "bulb"] and [g["material"] for g in groups] == ["red", "lamp", "nowhere"]
+    assert [(g["first_triangle"], g["num_triangles"]) for g in groups] == [(0, 2), (2, 1), (3, 2)] and tg.tolist() == [0, 0, 1, 2, 2]
+    assert np.allclose(groups[0]["Kd"], (0.9, 0.1, 0.1)) and groups[0]["Ns"] == 10.0 and groups[0]["illum"] == 1
+    assert np.allclose(groups[1]["Ke"], (4, 5, 6)) and groups[1]["illum"] == 2 and abs(groups[1]["Ni"] - 1.45) < 1e-6 and groups[1]["d"] == 0.5
+    assert np.allclose(groups[2]["Kd"], (0.8, 0.8, 0.8)) and np.allclose(groups[2]["Ke"], 0)      # unknown material: MTL defaults
+    assert i[3].tolist() == [4, 5, 6] and i[4].tolist() == [0, 4, 5]                                # relative and cross-object indices
+    # the shipped models: one object, one material each (Blender's lambert1, Kd 0.8)
+    _, idx, tg, groups = capi.load_obj_groups(os.path.join(helpers.REPO, "models", "cats.obj"))
+    assert idx.shape == (2196, 3) and len(groups) == 1 and groups[0]["material"] == "lambert1" and np.allclose(groups[0]["Kd"], 0.8)
+    v0, i0 = capi.load_obj(os.path.join(helpers.REPO, "models", "cats.obj"))
+    assert np.array_equal(i0, idx)
