@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -121,8 +122,10 @@ struct Builder {
     uint32_t max_leaf;
     std::vector<Ref> refs;
     FlatBvh &out;
-    static constexpr int NBINS = 16;
-    static constexpr double NODE_COST = 1.0, TRI_COST = 1.3;
+    static constexpr int NBINS = 64; // capacity; `nbins` are used
+    static constexpr double NODE_COST = 1.0;
+    double TRI_COST = 1.3;
+    int nbins = 16;
 
     Builder(const std::vector<HostTriangle> &t, const std::vector<uint32_t> &r, const std::vector<BvhSphere> &sp, uint32_t ml, FlatBvh &o)
         : tris(t), rank(r), spheres(sp), max_leaf(ml), out(o) {}
@@ -195,18 +198,18 @@ struct Builder {
                 const double ext = cb.mx[axis] - cb.mn[axis];
                 if (!(ext > 0)) continue;
                 DBox bb[NBINS]; size_t bc[NBINS];
-                for (int k = 0; k < NBINS; k++) { bb[k].reset(); bc[k] = 0; }
-                const double scale = NBINS / ext;
+                for (int k = 0; k < nbins; k++) { bb[k].reset(); bc[k] = 0; }
+                const double scale = nbins / ext;
                 for (size_t i = lo; i < hi; i++) {
                     int k = (int)((refs[i].c[axis] - cb.mn[axis]) * scale);
-                    k = std::min(std::max(k, 0), NBINS - 1);
+                    k = std::min(std::max(k, 0), nbins - 1);
                     bb[k].grow(to_d(refs[i].box)); bc[k]++;
                 }
                 double right_area[NBINS]; size_t right_cnt[NBINS];
                 DBox acc; acc.reset(); size_t cnt = 0;
-                for (int k = NBINS - 1; k > 0; k--) { acc.grow(bb[k]); cnt += bc[k]; right_area[k] = acc.area(); right_cnt[k] = cnt; }
+                for (int k = nbins - 1; k > 0; k--) { acc.grow(bb[k]); cnt += bc[k]; right_area[k] = acc.area(); right_cnt[k] = cnt; }
                 acc.reset(); cnt = 0;
-                for (int k = 0; k < NBINS - 1; k++) {
+                for (int k = 0; k < nbins - 1; k++) {
                     acc.grow(bb[k]); cnt += bc[k];
                     if (cnt == 0 || right_cnt[k + 1] == 0) continue;
                     const double cost = acc.area() * (double)cnt + right_area[k + 1] * (double)right_cnt[k + 1];
@@ -219,11 +222,11 @@ struct Builder {
                 const double leaf_cost = TRI_COST * (double)n;
                 if (n <= max_leaf && leaf_cost <= split_cost) return make_leaf(lo, hi);
                 const double ext = cb.mx[best_axis] - cb.mn[best_axis];
-                const double scale = NBINS / ext;
+                const double scale = nbins / ext;
                 const double mn = cb.mn[best_axis];
                 auto it = std::partition(refs.begin() + (long)lo, refs.begin() + (long)hi, [&](const Ref &r) {
                     int k = (int)((r.c[best_axis] - mn) * scale);
-                    k = std::min(std::max(k, 0), NBINS - 1);
+                    k = std::min(std::max(k, 0), nbins - 1);
                     return k <= best_bin;
                 });
                 mid = (size_t)(it - refs.begin());
@@ -278,6 +281,8 @@ void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t
     }
     const float margin = fmaxf(1e-5f, maxabs * 3.814697265625e-06f);
     Builder b(tris, rank, spheres, max_leaf, out);
+    if (const char *e = getenv("CRT_SAH_TRI_COST")) b.TRI_COST = atof(e);
+    if (const char *e = getenv("CRT_SAH_BINS")) b.nbins = std::min(std::max(atoi(e), 2), 64);
     b.refs.resize(tris.size() + spheres.size());
     for (size_t i = 0; i < b.refs.size(); i++) {
         Box bx;
