@@ -291,3 +291,42 @@ def test_gpu_lbvh_builder_on_the_1m_triangle_scene(capi, scenes):
     rgb_h, ids_h, st_h = host.render(cam, 480, 270, 2, want_ids=True)
     rgb_g, ids_g, st_g = gpu.render(cam, 480, 270, 2, want_ids=True)
     assert np.array_equal(ids_g, ids_h) and np.array_equal(rgb_g, rgb_h) and st_g.rays == st_h.rays
+
+
+def test_randomised_configurations_against_oracle(oracle, scenes, gpu_scenes, capi):
+    """A sweep over odd frame sizes, seeds, depths, sample windows, partitions and chunk counts: every one bit-exact against
+    the oracle (chunked runs against the oracle's chunk sums combined in chunk order)."""
+    rng = np.random.default_rng(20240611)
+    names = ["cat", "cats", "cat_checker", "random_spheres"]
+    for trial in range(14):
+        name = names[trial % len(names)]
+        desc, s = gpu_scenes(name)
+        width = int(rng.integers(9, 140))
+        height = max(1, int(width / (16 / 9)))          # the camera's own height (camera.h:27)
+        height = int(rng.integers(1, height + 1))       # or fewer rows
+        spp = int(rng.choice([1, 2, 3, 4, 8]))
+        kw = dict(max_depth=int(rng.integers(1, 12)), seed=int(rng.integers(0, 2 ** 40)), sample_offset=int(rng.integers(0, 50)))
+        kw["ids_sample"] = kw["sample_offset"] + int(rng.integers(0, spp))
+        camera = scenes.SPHERES_CAMERA if name == "random_spheres" else {}
+        params, cam = scenes.make_camera(width, **camera)
+        rs = oracle.RefScene(desc)
+        ocam = oracle.make_camera(params, width)
+        fb, rids, acc, rst = rs.render(ocam, width, height, spp, want_accum=True, **kw)
+        rgb, ids, st = s.render(cam, width, height, spp, want_ids=True, **kw)
+        assert np.array_equal(ids, rids) and np.array_equal(rgb.reshape(fb.shape), fb) and st.rays == rst.rays, (trial, name, width, height, spp, kw)
+        # tile partition, compact, gathered on the host
+        ranks = int(rng.integers(2, 6))
+        parts = [s.render(cam, width, height, spp, tile_rank=r, tile_ranks=ranks, flags=capi.OUT_COMPACT, **kw)[0] for r in range(ranks)]
+        assert np.array_equal(helpers.untile_numpy(np.concatenate(parts), width, height, ranks), fb), (trial, "tiles", ranks)
+        # sample chunks
+        chunks = [c for c in (2, 4, 8) if spp % c == 0]
+        if chunks:
+            n = int(rng.choice(chunks))
+            total = None
+            for c in range(n):
+                ckw = dict(kw)
+                ckw["sample_offset"] = kw["sample_offset"] + c * (spp // n)
+                _, _, a, _ = rs.render(ocam, width, height, spp // n, want_ids=False, want_accum=True, **ckw)
+                total = a.copy() if total is None else (total + a).astype(np.float32)
+            accn, idsn, stn = s.render(cam, width, height, spp, want_ids=True, flags=capi.OUT_ACCUM, sample_chunks=n, **kw)
+            assert np.array_equal(accn.reshape(total.shape), total) and np.array_equal(idsn, rids) and stn.rays == rst.rays, (trial, "chunks", n)
