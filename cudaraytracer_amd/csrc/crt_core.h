@@ -43,6 +43,12 @@ CRT_HD f3 cross(f3 a, f3 b)
 }
 CRT_HD float length(f3 a) { return __builtin_sqrtf(dot(a, a)); }
 CRT_HD f3 normalize(f3 a) { return a * (1.0f / __builtin_sqrtf(dot(a, a))); } // glm: v * inversesqrt(dot(v,v))
+// Comparisons of a length with a constant, without the square root.  sqrtf is correctly rounded and monotonic, so
+// sqrtf(x) < 1 <=> x < 1 (the root of the float below 1 rounds below 1) and sqrtf(x) <= 1e-8f <=> x <= CRT_SQ_1EM8, the
+// largest float whose root rounds to <= 1e-8f (tests/test_oracle.py walks the floats around both thresholds).
+#define CRT_SQ_1EM8 0x1.cd2b2ap-54f
+CRT_HD bool length_lt_1(float len2) { return len2 < 1.0f; }
+CRT_HD bool length_le_1em8(float len2) { return len2 <= CRT_SQ_1EM8; }
 
 // ---------------------------------------------------------------------------------------------------------
 // Philox4x32-10, counter = (pixel, sample, stage, block), key = seed.  Replaces curand XORWOW
@@ -244,7 +250,7 @@ CRT_HD bool scatter(int type, float param, f3 colour, f3 ray_d, f3 point, f3 nor
         const f3 ruv = random_unit_vector(u01(rnd.x), u01(rnd.y)); // shared by both: the wave evaluates it once
         if (type == MAT_LAMBERTIAN) { // material.h:24-34
             f3 dir = normal + ruv;
-            if (length(dir) <= 1e-8f) dir = normal;
+            if (length_le_1em8(dot(dir, dir))) dir = normal; // length(dir) <= 1e-8f
             nd = dir;
         } else { // material.h:44-51 (always scatters)
             const f3 reflected = reflect(ray_d, normal);
@@ -292,7 +298,7 @@ CRT_HD void camera_ray_from(const CameraPOD &cam, uint32_t i, uint32_t j, uint32
         float py = fma1(u01_16(w >> 16), 1.0f - -1.0f, -1.0f);
         uint32_t draw = 0;
         // draws 0..9 are tested; draw 10 is taken as is
-        while (draw < 10 && !(__builtin_sqrtf(fma1(0.0f, 0.0f, fma1(py, py, px * px))) < 1.0f)) {
+        while (draw < 10 && !length_lt_1(fma1(0.0f, 0.0f, fma1(py, py, px * px)))) { // glm::length(p) < 1
             draw++;
             const uint32_t word = draw + 1u;
             if ((word & 3u) == 0u) r = philox4x32_10(pixel, sample, 0u, word >> 2, k0, k1);

@@ -227,3 +227,20 @@ def test_golden_fixtures(oracle, scenes):
         np.allclose(fb.reshape(50, 8, 50, 8, 3).mean(axis=(1, 3)), g["tile_means_16spp"], rtol=0, atol=1e-6)
     import hashlib
     assert hashlib.sha256(fb.tobytes()).hexdigest() == str(g["sha256_16spp"])
+
+
+def test_length_thresholds_without_square_root():
+    """crt_core.h compares lengths with 1 and 1e-8 on the squared length (length_lt_1, length_le_1em8): the float
+    neighbourhoods of both thresholds agree with the reference's sqrt form (camera.h:111-119 via utility.h:100-109,
+    material.h:29)."""
+    def around(x, n=200000):
+        bits = np.array([x], dtype=np.float32).view(np.uint32)[0].astype(np.int64)
+        return (bits + np.arange(-n, n + 1)).astype(np.uint32).view(np.float32)
+    one = around(1.0)
+    assert np.array_equal(np.sqrt(one) < np.float32(1.0), one < np.float32(1.0))
+    thr = np.float32(float.fromhex("0x1.cd2b2ap-54"))
+    tiny = around(thr)
+    assert np.array_equal(np.sqrt(tiny) <= np.float32(1e-8), tiny <= thr)
+    coarse = np.float32(10.0) ** np.arange(-44, 38, dtype=np.float32)   # and far from them
+    assert np.array_equal(np.sqrt(coarse) <= np.float32(1e-8), coarse <= thr)
+    assert np.array_equal(np.sqrt(coarse) < np.float32(1.0), coarse < np.float32(1.0))
