@@ -37,7 +37,7 @@ WORKLOADS = {
 # /opt/skills/guides/MI355X_MICROARCH.md: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (= the 157.3 TFLOP/s fp32 spec / 2)
 VALU_PEAK_TLANEOPS_256CU = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
-DEFAULT_CHUNKS = 16
+DEFAULT_CHUNKS = 32  # same for every N: 1/8 of the frame per rank needs fine units (tools/rank_share.py), the whole frame does not mind
 
 
 def lane_ops(st):
@@ -98,8 +98,11 @@ def cpu_baseline(desc, cam_params, width, height, max_depth, seed, target_second
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames-in-flight", type=int, choices=[1, 2], default=2,
+                    help="2: consecutive frames alternate between two HIP streams (dist.py), so one frame's last waves drain while the next "
+                         "frame's first waves start; 1: one frame at a time")
     ap.add_argument("--mode", choices=["tile", "sample"], default="tile")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cats")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug; invalidates the headline number)")
@@ -135,17 +138,17 @@ def main():
     while spp % chunks:
         chunks //= 2
     if args.mode == "tile":
-        frame = TileFrame(W, H, world, rank, device, sample_chunks=chunks)
+        frame = TileFrame(W, H, world, rank, device, sample_chunks=chunks, pipelined=args.frames_in_flight == 2)
 
-        def launch(want_stats=False, flags=0):
-            return frame.render_local(scene, cam, spp, depth, seed, want_stats=want_stats, flags=flags)
-        finish = frame.gather
+        def launch(want_stats=False, flags=0, timing=None):
+            return frame.render_local(scene, cam, spp, depth, seed, want_stats=want_stats, flags=flags, timing=timing)
+        finish = frame.gather_async  # two frames in flight on two streams (dist.py): drain() completes the last ones
     else:
-        frame = SampleFrame(W, H, spp, world, rank, device, sample_chunks=chunks)
+        frame = SampleFrame(W, H, spp, world, rank, device, sample_chunks=chunks, pipelined=args.frames_in_flight == 2)
 
-        def launch(want_stats=False, flags=0):
-            return frame.render_local(scene, cam, depth, seed, want_stats=want_stats)
-        finish = frame.reduce
+        def launch(want_stats=False, flags=0, timing=None):
+            return frame.render_local(scene, cam, depth, seed, want_stats=want_stats, flags=flags, timing=timing)
+        finish = frame.reduce_async
 
     def barrier():
         torch.cuda.synchronize()
@@ -156,21 +159,26 @@ def main():
     for _ in range(args.warmup):
         launch()
         finish()
+    frame.drain()
     barrier()
-    # HIP events on the launch stream (= torch's current stream, handed to crt_render) around every render call of the
-    # timed region; nothing inside the region waits on the host
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # Nothing inside the timed region waits on the host.
     t0 = time.perf_counter()
-    for e0, e1 in events:
-        e0.record()
+    for _ in range(args.steps):
         launch()
-        e1.record()
         finish()
+    frame.drain()  # every one of the K frames is assembled (tile: on every rank; sample: on rank 0) inside the timed region
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in events]
-    rays_local = launch(want_stats=True).rays  # deterministic: the same frame again, outside the timed region
-    finish()
+    # The kernel's own launch duration for the roofline: HIP events on the launch stream around the kernel (recorded by
+    # the library, crt_stats.kernel_ms), over launches that run alone -- with two frames in flight a kernel's start-to-end
+    # time includes the wait for the wave slots of the frame before it, which says nothing about the kernel.
+    kernel_ms, rays_local = [], 0
+    for _ in range(3):
+        st = launch(want_stats=True)
+        finish()
+        frame.drain()
+        kernel_ms.append(st.kernel_ms)
+        rays_local = st.rays  # deterministic: the same frame again
 
     t = torch.tensor([elapsed, float(rays_local), sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=device)
     if world > 1:
@@ -183,11 +191,9 @@ def main():
         rays_frame, kernel_avg_ms = float(rays_local), float(t[2])
 
     # work counts of this rank's launch (instrumented kernel, outside the timed region; counts are deterministic)
-    if args.mode == "tile":
-        stw = frame.render_local(scene, cam, spp, depth, seed, want_stats=True, flags=capi.COUNT_WORK)
-    else:
-        stw = scene.render(cam, W, H, frame.spp_local, max_depth=depth, seed=seed, sample_offset=rank * frame.spp_local,
-                           flags=capi.OUT_ACCUM | capi.COUNT_WORK, out_rgb=frame.accum.data_ptr(), want_stats=True, sample_chunks=frame.sample_chunks)[2]
+    stw = launch(want_stats=True, flags=capi.COUNT_WORK)
+    finish()
+    frame.drain()
     torch.cuda.synchronize()
 
     if rank == 0:
@@ -204,11 +210,11 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d %dspp depth %d (models/%s + ground + emissive sphere, seed %d)" %
                        (args.workload, W, H, spp, depth, {"cats": "cats.obj", "random_spheres": "no mesh"}.get(builder, "cat.obj"), seed),
-                       "partition": "%s x%d" % (args.mode, world), "sample_chunks": chunks if args.mode == "tile" else frame.sample_chunks, "triangles": info.num_triangles, "bvh_nodes": info.num_nodes,
+                       "partition": "%s x%d" % (args.mode, world), "frames_in_flight": frame.slots.n, "sample_chunks": chunks if args.mode == "tile" else frame.sample_chunks, "triangles": info.num_triangles, "bvh_nodes": info.num_nodes,
                        "rays_per_frame": int(rays_frame), "device_cus": cus},
             "roofline": {"bound": "valu", "achieved": ops / ksec / 1e12, "peak": valu_peak, "unit": "Tlane-op/s",
                          "frac": ops / ksec / 1e12 / valu_peak, "traffic": traffic,
-                         "kernel": "render_kernel", "kernel_ms": kernel_avg_ms, "rays_per_launch": int(stw.rays),
+                         "kernel": "render_kernel", "kernel_ms": kernel_avg_ms, "kernel_ms_note": "mean of 3 launches that run alone, right after the timed region", "rays_per_launch": int(stw.rays),
                          "nodes_per_ray": stw.nodes / max(stw.rays, 1), "tri_tests_per_ray": stw.tri_tests / max(stw.rays, 1),
                          "hbm": {"bound": "hbm", "achieved": (traffic / ksec / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": (traffic / ksec / 1e9 / HBM_PEAK_GBS) if traffic else None,

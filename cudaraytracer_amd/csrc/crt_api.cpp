@@ -240,12 +240,36 @@ struct crt_scene {
     uint32_t builder = 0; float build_ms = 0.0f;
     std::vector<Sphere> flat_spheres; // the spheres that are tested before the walk (the others are slots of the tree)
     void *d_nodes = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_shades = nullptr;
-    unsigned long long *d_counters = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     uint32_t max_waves = 0; // persistent-grid size: compute units x wave slots
     SceneView view{};
-    // sample-chunk slabs (grow only): chunks x frame floats, summed in chunk order by finalize_chunks_kernel
-    float *d_chunk_slabs = nullptr; size_t chunk_slab_floats = 0;
+    // Per-stream scratch: work counters, sample-chunk slabs (grow only: chunks x frame floats, summed in chunk order by
+    // finalize_chunks_kernel) and the timing events.  Calls on one stream are ordered and share a set; calls on different
+    // streams get different sets, so their kernels may overlap (the next frame fills the GPU while this one's last waves drain).
+    struct StreamScratch {
+        hipStream_t stream = nullptr; bool used = false, recorded = false; uint64_t last_use = 0;
+        unsigned long long *d_counters = nullptr;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr; // around the render kernel; after the last use of the set
+        float *d_chunk_slabs = nullptr; size_t chunk_slab_floats = 0;
+    };
+    static constexpr int MAX_STREAMS = 4;
+    StreamScratch scratch[MAX_STREAMS];
+    uint64_t use_clock = 0;
+    // The set of `stream`; a stream seen for the first time takes a free set or else the least recently used one, whose
+    // last render it then waits for (*handover = that render's end event).
+    StreamScratch *scratch_for(hipStream_t stream, hipEvent_t *handover)
+    {
+        *handover = nullptr;
+        StreamScratch *pick = nullptr;
+        for (StreamScratch &x : scratch) if (x.used && x.stream == stream) pick = &x;
+        if (!pick) for (StreamScratch &x : scratch) if (!x.used) { pick = &x; break; }
+        if (!pick) {
+            pick = &scratch[0];
+            for (StreamScratch &x : scratch) if (x.last_use < pick->last_use) pick = &x;
+            if (pick->recorded) *handover = pick->ev_done;
+        }
+        pick->used = true; pick->stream = stream; pick->last_use = ++use_clock;
+        return pick;
+    }
     // staging for host-pointer renders (grow only)
     float *d_stage_rgb = nullptr; size_t stage_rgb_floats = 0;
     int *d_stage_ids = nullptr; size_t stage_ids = 0;
@@ -253,14 +277,18 @@ struct crt_scene {
     void release_device()
     {
         if (device >= 0) (void)hipSetDevice(device);
-        void *ptrs[] = { d_nodes, d_tris, d_spheres, d_shades, d_counters, d_stage_rgb, d_stage_ids, d_chunk_slabs };
+        void *ptrs[] = { d_nodes, d_tris, d_spheres, d_shades, d_stage_rgb, d_stage_ids };
         for (void *p : ptrs) if (p) (void)hipFree(p);
-        d_nodes = d_tris = d_spheres = d_shades = nullptr; d_counters = nullptr; d_stage_rgb = nullptr; d_stage_ids = nullptr;
+        d_nodes = d_tris = d_spheres = d_shades = nullptr; d_stage_rgb = nullptr; d_stage_ids = nullptr;
         stage_rgb_floats = stage_ids = 0;
-        d_chunk_slabs = nullptr; chunk_slab_floats = 0;
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        ev0 = ev1 = nullptr;
+        for (StreamScratch &x : scratch) {
+            if (x.d_counters) (void)hipFree(x.d_counters);
+            if (x.d_chunk_slabs) (void)hipFree(x.d_chunk_slabs);
+            if (x.ev0) (void)hipEventDestroy(x.ev0);
+            if (x.ev1) (void)hipEventDestroy(x.ev1);
+            if (x.ev_done) (void)hipEventDestroy(x.ev_done);
+            x = StreamScratch();
+        }
         committed = false;
     }
 };
@@ -502,15 +530,12 @@ extern "C" int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags)
     if ((rc = upload(&s->d_tris, s->bvh.tris))) return rc;
     if ((rc = upload(&s->d_spheres, spheres))) return rc;
     if ((rc = upload(&s->d_shades, s->shades))) return rc;
-    HIP_TRY(hipMalloc((void **)&s->d_counters, CRT_COUNTER_BYTES));
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
-        s->max_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)std::min(std::max(get_env_int("CRT_WAVES_PER_CU", 32), 1), 64);
+        // 20 = the waves of the render kernel a compute unit holds (96 VGPRs: 5 per SIMD); more would only queue up behind them
+        s->max_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)std::min(std::max(get_env_int("CRT_WAVES_PER_CU", 20), 1), 64);
     }
-    HIP_TRY(hipEventCreate(&s->ev0));
-    HIP_TRY(hipEventCreate(&s->ev1));
-
     SceneView &v = s->view;
     v.nodes = (const q4 *)s->d_nodes; v.tris = (const q4 *)s->d_tris; v.spheres = (const Sphere *)s->d_spheres;
     v.shades = (const Shade *)s->d_shades;
@@ -621,6 +646,15 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
         return fail(CRT_ERR_INVALID, "crt_render: sample_chunks must be a power of two (<= 1024) that divides spp");
     HIP_TRY(hipSetDevice(s->device));
     hipStream_t stream = (hipStream_t)p->stream;
+    hipEvent_t handover = nullptr;
+    crt_scene::StreamScratch *x = s->scratch_for(stream, &handover);
+    if (handover) HIP_TRY(hipStreamWaitEvent(stream, handover, 0)); // the set's previous owner finishes first
+    if (!x->d_counters) {
+        HIP_TRY(hipMalloc((void **)&x->d_counters, CRT_COUNTER_BYTES));
+        HIP_TRY(hipEventCreate(&x->ev0));
+        HIP_TRY(hipEventCreate(&x->ev1));
+        HIP_TRY(hipEventCreate(&x->ev_done));
+    }
 
     RenderArgs ra{};
     ra.width = p->width; ra.height = p->height; ra.tiles_x = (p->width + 7u) / 8u; ra.tiles_y = (p->height + 7u) / 8u;
@@ -670,36 +704,44 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
         const uint64_t units = (uint64_t)((ra.tiles_x * ra.tiles_y + ra.tile_ranks - 1) / ra.tile_ranks) * 64u * chunks;
         if (units >= (1ull << 31)) return fail(CRT_ERR_LIMIT, "crt_render: pixels x sample_chunks does not fit the work counter");
         const size_t need = rgb_floats * chunks;
-        if (s->chunk_slab_floats < need) {
-            if (s->d_chunk_slabs) (void)hipFree(s->d_chunk_slabs);
-            s->d_chunk_slabs = nullptr; s->chunk_slab_floats = 0;
-            HIP_TRY(hipMalloc((void **)&s->d_chunk_slabs, need * sizeof(float)));
-            s->chunk_slab_floats = need;
+        if (x->chunk_slab_floats < need) {
+            if (x->d_chunk_slabs) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(x->d_chunk_slabs); }
+            x->d_chunk_slabs = nullptr; x->chunk_slab_floats = 0;
+            HIP_TRY(hipMalloc((void **)&x->d_chunk_slabs, need * sizeof(float)));
+            x->chunk_slab_floats = need;
         }
         // a partial row-major render (tile_ranks > 1 without CRT_OUT_COMPACT) leaves other ranks' pixels untouched
         if (p->tile_ranks > 1 && !(p->flags & CRT_OUT_COMPACT))
             return fail(CRT_ERR_INVALID, "crt_render: sample_chunks with tile_ranks > 1 needs CRT_OUT_COMPACT");
-        d_target = s->d_chunk_slabs;
+        d_target = x->d_chunk_slabs;
         ra.flags |= (uint32_t)RA_ACCUM;
     }
 
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, CRT_COUNTER_BYTES, stream));
-    HIP_TRY(hipEventRecord(s->ev0, stream));
-    HIP_TRY(launch_render(s->view, *reinterpret_cast<const CameraPOD *>(cam), ra, d_target, d_ids, s->d_counters, (p->flags & CRT_COUNT_WORK) != 0, s->max_waves, stream));
-    if (chunks > 1) HIP_TRY(launch_finalize_chunks(s->d_chunk_slabs, chunks, rgb_floats, p->spp, (p->flags & CRT_OUT_ACCUM) != 0, d_rgb, stream));
-    HIP_TRY(hipEventRecord(s->ev1, stream));
+    HIP_TRY(hipMemsetAsync(x->d_counters, 0, CRT_COUNTER_BYTES, stream));
+    HIP_TRY(hipEventRecord(x->ev0, stream));
+    HIP_TRY(launch_render(s->view, *reinterpret_cast<const CameraPOD *>(cam), ra, d_target, d_ids, x->d_counters, (p->flags & CRT_COUNT_WORK) != 0, s->max_waves, stream));
+    HIP_TRY(hipEventRecord(x->ev1, stream));
+    if (chunks > 1) HIP_TRY(launch_finalize_chunks(x->d_chunk_slabs, chunks, rgb_floats, p->spp, (p->flags & CRT_OUT_ACCUM) != 0, d_rgb, stream));
+    HIP_TRY(hipEventRecord(x->ev_done, stream));
+    x->recorded = true;
 
     if (!rgb_on_device) HIP_TRY(hipMemcpyAsync(out_rgb, d_rgb, rgb_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
     if (out_ids && !ids_on_device) HIP_TRY(hipMemcpyAsync(out_ids, d_ids, npix * sizeof(int), hipMemcpyDeviceToHost, stream));
     if (stats) {
-        unsigned long long c[24];
-        HIP_TRY(hipMemcpyAsync(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
+        unsigned long long c[32];
+        HIP_TRY(hipMemcpyAsync(c, x->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipStreamSynchronize(stream));
         memset(stats, 0, sizeof *stats);
         stats->rays = c[0]; stats->nodes = c[1]; stats->tri_tests = c[2]; stats->sphere_tests = c[3]; stats->tie_refolds = c[4]; stats->shaded_hits = c[5];
         for (int k = 0; k < 10; k++) stats->sched[k] = c[8 + k];
+        if ((p->flags & CRT_COUNT_WORK) && get_env_int("CRT_PRINT_SECTIONS", 0)) { // tuning aid: where the waves of the instrumented kernel spend their time
+            static const char *const name[9] = { "votes", "hit+shade", "store+fetch", "philox", "scatter", "camera", "spheres+root box", "node steps", "leaf steps" };
+            unsigned long long total = 0;
+            for (int k = 0; k < 9; k++) total += c[18 + k];
+            for (int k = 0; k < 9; k++) fprintf(stderr, "crt sections: %-17s %5.1f %%\n", name[k], total ? 100.0 * (double)c[18 + k] / (double)total : 0.0);
+        }
         float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        HIP_TRY(hipEventElapsedTime(&ms, x->ev0, x->ev1));
         stats->kernel_ms = ms;
     } else if (!rgb_on_device || (out_ids && !ids_on_device)) {
         HIP_TRY(hipStreamSynchronize(stream)); // host buffers must be complete on return

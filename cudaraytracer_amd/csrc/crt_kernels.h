@@ -29,7 +29,9 @@ struct RenderArgs {
     uint32_t bvh_depth;       // levels of the triangle BVH (selects the LDS stack size)
 };
 
-// counters: 24 x uint64 ([8..17] = wave-level schedule counters, crt_stats.sched) on the device: [0] rays [1] nodes [2] triangle tests [3] sphere tests [4] tie refolds [5] shaded hits [6] pixel work counter
+// counters: 32 x uint64 on the device: [0] rays [1] nodes [2] triangle tests [3] sphere tests [4] tie refolds [5] shaded hits [6] pixel work counter
+// (pool kernel) [8..17] wave-level schedule counters (crt_stats.sched) [18..26] section clocks (CRT_PRINT_SECTIONS) [28] block counters used up
+#define CRT_COUNTER_USED_UP 28
 // bytes of the counter buffer: 32 x uint64 (the above, padded) + 64 block counters of the work queue, 256 B apart
 #define CRT_COUNTER_BYTES (32 * 8 + 64 * 256)
 hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,

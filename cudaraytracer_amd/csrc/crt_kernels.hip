@@ -102,6 +102,25 @@ __device__ __forceinline__ T load_kernel_arg(size_t offset)
     return r.v;
 }
 
+// Section clock of the instrumented kernel (CRT_COUNT_WORK): shader-clock ticks a wave spends in each part of the loop
+template <bool ON>
+struct SectionClock {
+    unsigned long long sum[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, last = 0;
+    __device__ __forceinline__ void start() { if constexpr (ON) { __builtin_amdgcn_sched_barrier(0); last = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } }
+    template <int K>
+    __device__ __forceinline__ void lap()
+    {
+        if constexpr (ON) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("; crt_section_end %0" ::"n"(K)); // a marker for tools/isa_sections.py
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_sched_barrier(0);
+            sum[K] += now - last; last = now;
+        }
+    }
+};
+#define CRT_LAP(clk, k) (clk).template lap<k>()
+
 // Lane phases while not walking (a lane walks the BVH iff tv.cur != CRT_BVH_NONE)
 enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
 
@@ -176,6 +195,8 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
     uint32_t wc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // schedule counters, lane 0 only (COUNT_WORK)
     unsigned long long t_start = 0;
     if constexpr (COUNT_WORK) t_start = wall_clock64(); // 100 MHz
+    SectionClock<COUNT_WORK> clk; // [0] votes [1] hit + shade [2] store + fetch [3] Philox [4] scatter [5] camera [6] spheres + root box [7] node steps [8] leaf steps
+    clk.start();
 
     for (;;) {
         const bool walking = tv.cur != CRT_BVH_NONE;
@@ -185,6 +206,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
         if (nready >= threshold || nwalk == 0) {
             // ================================ phase A ================================
             if constexpr (COUNT_WORK) { if (lane == 0) { wc[0]++; wc[1] += nready; } }
+            CRT_LAP(clk, 0);
             const bool active = !walking && phase != P_DONE;
             bool want_scatter = false;
             Surface sf;
@@ -218,6 +240,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                     phase = s_idx < s_end ? P_NEW : P_FETCH;
                 }
             }
+            CRT_LAP(clk, 1);
             // ---- work queue, wave-uniform: finished units are stored, new ones come from the wave's current block.
             // Atomics on one address are served ~5 ns apart device-wide and every wave waits its turn (measured: 2 M per
             // frame cost 10 ms), hence blocks, and several counters.
@@ -238,21 +261,32 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                 uint32_t fresh = total, fresh_end = total;
                 if (n_need > left) {
                     const int leader = __builtin_ctzll(fm);
+                    // blocks_per_stripe = 0: block b of counter k is global block b * stripes + k (all counters walk the frame
+                    // together); else counter k owns the contiguous blocks [k * bps, (k + 1) * bps) (a band of the frame)
+                    const uint32_t bps = rak.blocks_per_stripe, nblocks = (total + CRT_FETCH_BLOCK - 1u) / CRT_FETCH_BLOCK;
                     while (stripes_left > 0) {
+                        // blocks of this counter
+                        const uint32_t mine = bps ? (nblocks > stripe * bps ? (nblocks - stripe * bps < bps ? nblocks - stripe * bps : bps) : 0u)
+                                                  : (nblocks + CRT_WORK_STRIPES - 1u - stripe) / CRT_WORK_STRIPES;
                         uint32_t b = 0;
                         if ((int)lane == leader) b = atomicAdd(work + stripe * 64u, 1u);
                         b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
-                        // blocks_per_stripe = 0: block b of counter k is global block b * stripes + k (all counters walk the
-                        // frame together); else counter k owns the contiguous blocks [k * bps, (k + 1) * bps) (a band of the frame)
-                        const uint32_t bps = rak.blocks_per_stripe;
-                        const unsigned long long lo = (bps ? (unsigned long long)stripe * bps + b : (unsigned long long)b * CRT_WORK_STRIPES + stripe) * CRT_FETCH_BLOCK;
-                        if (lo < total && (bps == 0 || b < bps)) {
-                            fresh = (uint32_t)lo;
+                        if (b < mine) {
+                            fresh = (bps ? stripe * bps + b : b * CRT_WORK_STRIPES + stripe) * CRT_FETCH_BLOCK;
                             fresh_end = total - fresh > CRT_FETCH_BLOCK ? fresh + CRT_FETCH_BLOCK : total;
                             break;
                         }
-                        // this counter is used up: first the other counters with the same index mod 8 (workgroups go round
-                        // robin over the 8 XCDs, so those are the bands this XCD's L2 already serves), then the next residue
+                        // This counter is used up.  The wave that is the first to see that (b == mine) counts it in `used_up`;
+                        // once all 64 are counted there is nothing left anywhere and a wave stops looking: without this every
+                        // wave ends the frame by trying all 64 counters, one serialised atomic round trip each.
+                        unsigned int *used_up = reinterpret_cast<unsigned int *>(counters + CRT_COUNTER_USED_UP);
+                        if ((int)lane == leader && b == mine) atomicAdd(used_up, 1u);
+                        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(used_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >= CRT_WORK_STRIPES) {
+                            stripes_left = 0;
+                            break;
+                        }
+                        // else the next counter: first the ones with the same index mod 8 (workgroups go round robin over the 8
+                        // XCDs, so those are the bands this XCD's L2 already serves), then the next residue
                         stripes_left--;
                         const uint32_t seen = CRT_WORK_STRIPES - stripes_left, s0 = blockIdx.x % CRT_WORK_STRIPES;
                         stripe = ((((s0 >> 3) + seen) & 7u) << 3) | (((s0 & 7u) + (seen >> 3)) & 7u);
@@ -297,12 +331,14 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                     }
                 }
             }
+            CRT_LAP(clk, 2);
             if (active) {
                 bool has_ray = false;
                 // one Philox evaluation for both kinds of lane: stage 1 + depth for a scatter, stage 0 block 0 for a camera ray
                 u4 r;
                 r.x = r.y = r.z = r.w = 0u;
                 if (want_scatter || phase == P_NEW) r = philox4x32_10(pixel, ra.sample_offset + s_idx, want_scatter ? 1u + depth : 0u, 0u, ra.key0, ra.key1);
+                CRT_LAP(clk, 3);
                 if (want_scatter) {
                     f3 att, no, nd;
                     scatter(m_type, m_param, colour, p.d, sf.point, sf.normal, sf.front_face, r, att, no, nd);
@@ -311,6 +347,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                     depth++;
                     has_ray = true;
                 }
+                CRT_LAP(clk, 4);
                 if (phase == P_NEW) {
                     const CameraPOD camk = load_kernel_arg<CameraPOD>(offsetof(KernelArgsLayout, cam));
                     camera_ray_from(camk, i, j, pixel, ra.sample_offset + s_idx, ra.key0, ra.key1, r, p.o, p.d);
@@ -320,6 +357,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                     path_prim = -1;
                     has_ray = true;
                 }
+                CRT_LAP(clk, 5);
                 if (has_ray) {
                     cnt.ray();
                     hit.t = FLT_MAX; hit.code = -1; hit.near_tie = false;
@@ -327,6 +365,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                     phase = P_HIT; // what the lane does once tv.cur is CRT_BVH_NONE again (at once if the root box is missed)
                 }
             }
+            CRT_LAP(clk, 6);
         } else {
             // ================================ phase B ================================
             const int alive = nready + nwalk;
@@ -335,6 +374,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                 const int n_inner = popc64(__ballot(inner)), n_leaf = popc64(__ballot(leaf));
                 const int nw = n_inner + n_leaf;
                 if (nw == 0 || alive - nw >= threshold) break;
+                CRT_LAP(clk, 0);
                 if (n_inner >= n_leaf) {
                     if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_inner; } }
                     if (inner) trav_inner(sc, tv, stack, cnt);
@@ -345,9 +385,11 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                         if constexpr (COUNT_WORK) { const int na = popc64(__ballot(inner && again)); if (lane == 0) { wc[4]++; wc[5] += na; } }
                         if (inner && again) trav_inner(sc, tv, stack, cnt);
                     }
+                    CRT_LAP(clk, 7);
                 } else {
                     if constexpr (COUNT_WORK) { if (lane == 0) { wc[6]++; wc[7] += n_leaf; } }
                     if (leaf) trav_leaf<MODE_CLOSEST>(sc, p.o, p.d, tmin, hit, 0, 0.0f, tv, stack, cnt);
+                    CRT_LAP(clk, 8);
                 }
             }
         }
@@ -377,6 +419,8 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
             atomicAdd(&counters[16], 1ull);
             atomicAdd(&counters[17], dt);
             atomicMax(&counters[10], dt);
+#pragma unroll
+            for (int k = 0; k < 9; k++) atomicAdd(&counters[18 + k], clk.sum[k]); // section clocks (CRT_PRINT_SECTIONS)
         }
     }
 }

@@ -158,7 +158,7 @@ typedef struct crt_stats {
     uint64_t sched[10];     /* schedule counters (CRT_COUNT_WORK): [0] shade-phase runs [1] lanes in them [2] longest wave
                                lifetime, 10 ns ticks [4] node steps [5] lanes in them [6] leaf steps [7] lanes in them
                                [8] waves that rendered pixels [9] sum of their lifetimes, 10 ns ticks               */
-    float kernel_ms;        /* hipEvent time of the render kernel on `stream`                               */
+    float kernel_ms;        /* hipEvent time of the render kernel alone (not the chunk-sum pass) on `stream` */
     uint32_t reserved;
 } crt_stats;
 
@@ -167,7 +167,11 @@ typedef struct crt_stats {
  * with CRT_OUT_COMPACT); out_ids (nullable): width*height int32 primary-hit primitive ids of sample
  * `ids_sample` (-1 = miss).  Both may be device pointers (any HIP allocation on the scene's device) or host
  * pointers (staged through an internal device buffer).  With stats != NULL the call synchronises `stream`
- * before returning; with stats == NULL and device pointers it is asynchronous on `stream`. */
+ * before returning; with stats == NULL and device pointers it is asynchronous on `stream`.
+ * Calls on one stream run in order.  Calls on different streams may overlap on the GPU: the scene keeps one set of
+ * scratch buffers (work counters, chunk slabs) per stream, up to four sets; a fifth stream takes over the least recently
+ * used set and waits for that set's last render.  The render kernel is persistent and fills the GPU, so what overlaps is
+ * the end of one frame with the start of the next (dist.py and bench.py keep two frames in flight this way). */
 int crt_render(const crt_scene *s, const crt_camera *cam, const crt_render_params *p, float *out_rgb, int32_t *out_ids,
                crt_stats *stats);
 

@@ -7,7 +7,7 @@ TAG=${1:-r1}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-}"   # BENCH_ARGS="--workload cat_grid" profiles another workload
+BENCH="python3 bench.py --steps 3 --warmup 1 --frames-in-flight 1 --no-cpu-baseline ${BENCH_ARGS:-}"   # BENCH_ARGS="--workload cat_grid" profiles another workload
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "trace failed"; tail -5 $OUT/trace.log; exit 1; }
 pass() { # name, counters...
   local name=$1; shift

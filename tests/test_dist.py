@@ -4,6 +4,7 @@ No GPU here, so each rank produces its share with the test-only host single-step
 compiled for the host) and the de-interleave / finalize epilogues are numpy stand-ins supplied by the test; what is
 under test is dist.py's partitioning, buffer sizing and collectives, against the oracle's full frame.
 """
+import ctypes
 import os
 import socket
 
@@ -42,35 +43,78 @@ def _worker(rank, world, port, mode, outdir):
         v = acc.numpy() / np.float32(spp)
         frame.copy_(torch.from_numpy(np.where(v > 0, np.sqrt(v), np.float32(0)).astype(np.float32)))
 
-    if mode == "tile":
-        f = TileFrame(W, H, world, rank, torch.device("cpu"), untile_fn=untile)
-        part, _, st = hs.render(s, cam, W, H, SPP, tile_rank=rank, tile_ranks=world)
-        f.local.copy_(torch.from_numpy(helpers.to_compact(part, rank, world)))
-        frame = f.gather()
+    class Stats:
+        rays = 0
+
+    class HostScene:
+        """Stands in for capi.Scene: the host single-stepper renders what dist.py asks for into the buffer it names."""
+        def render(self, cam, width, height, spp, max_depth=10, seed=1984, sample_offset=0, tile_rank=0, tile_ranks=1, flags=0,
+                   out_rgb=None, want_stats=False, stream=None, sample_chunks=0):
+            from cudaraytracer_amd import capi
+            part, _, st = hs.render(s, cam, width, height, spp, max_depth=max_depth, seed=seed, sample_offset=sample_offset,
+                                    tile_rank=tile_rank, tile_ranks=tile_ranks, flags=flags & capi.OUT_ACCUM)
+            data = helpers.to_compact(part, tile_rank, tile_ranks) if flags & capi.OUT_COMPACT else part.reshape(-1)
+            data = np.ascontiguousarray(data, dtype=np.float32).reshape(-1)
+            ctypes.memmove(out_rgb, data.ctypes.data, data.nbytes)
+            Stats.rays = st["rays"]
+            return None, None, Stats
+
+    scene = HostScene()
+    first = None
+    if mode.startswith("tile"):
+        f = TileFrame(W, H, world, rank, torch.device("cpu"), untile_fn=untile, pipelined=mode.endswith("pipelined"))
+        if mode.endswith("pipelined"):   # three frames over two slots: starting frame 2 finishes frame 0 (seed 7)
+            for seed in (7, 11, 1984):
+                f.render_local(scene, cam, SPP, 10, seed)
+                if seed == 1984:
+                    first = f.frame.clone()
+                f.gather_async()
+            frame = f.drain()
+        else:
+            f.render_local(scene, cam, SPP, 10, 1984)
+            frame = f.gather()
     else:
-        f = SampleFrame(W, H, SPP, world, rank, torch.device("cpu"), finalize_fn=finalize)
-        part, _, st = hs.render(s, cam, W, H, f.spp_local, sample_offset=rank * f.spp_local, flags=1)
-        f.accum.copy_(torch.from_numpy(part.reshape(-1)))
-        frame = f.reduce()
+        f = SampleFrame(W, H, SPP, world, rank, torch.device("cpu"), finalize_fn=finalize, pipelined=mode.endswith("pipelined"))
+        if mode.endswith("pipelined"):
+            for seed in (7, 11, 1984):
+                f.render_local(scene, cam, 10, seed)
+                if seed == 1984:
+                    first = f.frame.clone()
+                f.reduce_async()
+            frame = f.drain()
+        else:
+            f.render_local(scene, cam, 10, 1984)
+            frame = f.reduce()
+    st = {"rays": Stats.rays}
+    if first is not None and (mode.startswith("tile") or rank == 0):
+        np.save(os.path.join(outdir, "first_%s_%d.npy" % (mode, rank)), first.numpy().reshape(H, W, 3))
     rays = torch.tensor([st["rays"]], dtype=torch.int64)
     dist.all_reduce(rays)
-    if mode == "tile" or rank == 0:
+    if mode.startswith("tile") or rank == 0:
         np.save(os.path.join(outdir, "frame_%s_%d.npy" % (mode, rank)), frame.numpy().reshape(H, W, 3))
     if rank == 0:
         np.save(os.path.join(outdir, "rays_%s.npy" % mode), rays.numpy())
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,world", [("tile", 2), ("tile", 3), ("sample", 2)])
+@pytest.mark.parametrize("mode,world", [("tile", 2), ("tile", 3), ("sample", 2), ("tile_pipelined", 2), ("sample_pipelined", 2)])
 def test_frame_assembly_over_gloo(oracle, scenes, hostsim, tmp_path, mode, world):
     mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
     desc = scenes.cats()
     params, _ = scenes.make_camera(W)
-    fb, _, _, st = oracle.RefScene(desc).render(oracle.make_camera(params, W), W, H, SPP)
+    rs = oracle.RefScene(desc)
+    fb, _, _, st = rs.render(oracle.make_camera(params, W), W, H, SPP)
     assert int(np.load(tmp_path / ("rays_%s.npy" % mode))[0]) == st.rays
-    if mode == "tile":
+    if mode.startswith("tile"):
         for r in range(world):   # every rank holds the whole frame, bitwise equal to the single-process oracle frame
-            assert np.array_equal(np.load(tmp_path / ("frame_tile_%d.npy" % r)), fb)
+            assert np.array_equal(np.load(tmp_path / ("frame_%s_%d.npy" % (mode, r))), fb)
     else:                        # sample split: float sum order differs -> within 2 ulp of the gamma-encoded value
-        got = np.load(tmp_path / "frame_sample_0.npy")
+        got = np.load(tmp_path / ("frame_%s_0.npy" % mode))
         assert np.allclose(got, fb, rtol=3e-7, atol=1e-7)
+    if mode.endswith("pipelined"):   # the frame that was in flight while the second one was produced (seed 7)
+        fb7 = rs.render(oracle.make_camera(params, W), W, H, SPP, seed=7)[0]
+        if mode.startswith("tile"):
+            for r in range(world):
+                assert np.array_equal(np.load(tmp_path / ("first_%s_%d.npy" % (mode, r))), fb7)
+        else:
+            assert np.allclose(np.load(tmp_path / ("first_%s_0.npy" % mode)), fb7, rtol=3e-7, atol=1e-7)
