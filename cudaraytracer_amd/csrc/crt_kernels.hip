@@ -873,11 +873,15 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
 #undef CRT_LAUNCH_POOL
         return hipGetLastError();
     }
-    const bool shallow = ra.bvh_depth <= 16, ss = sc.sphere_slots != 0;
+    // the LDS stack is sized by the tree: 16 levels (4.6 KB per wave), 24 (6.7 KB: still the 20 waves per CU the registers
+    // allow) or 32 (8.7 KB: 18 waves per CU)
+    const bool ss = sc.sphere_slots != 0;
+    const int levels = ra.bvh_depth <= 16 ? 16 : ra.bvh_depth <= 24 ? 24 : CRT_STACK_DEPTH;
 #define CRT_LAUNCH(CW, SD, SS) hipLaunchKernelGGL((render_kernel<CW, SD, SS>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters)
 #define CRT_LAUNCH_SS(CW, SD) do { if (ss) CRT_LAUNCH(CW, SD, true); else CRT_LAUNCH(CW, SD, false); } while (0)
-    if (count_work) { if (shallow) CRT_LAUNCH_SS(true, 16); else CRT_LAUNCH_SS(true, CRT_STACK_DEPTH); }
-    else { if (shallow) CRT_LAUNCH_SS(false, 16); else CRT_LAUNCH_SS(false, CRT_STACK_DEPTH); }
+#define CRT_LAUNCH_SD(CW) do { if (levels == 16) CRT_LAUNCH_SS(CW, 16); else if (levels == 24) CRT_LAUNCH_SS(CW, 24); else CRT_LAUNCH_SS(CW, CRT_STACK_DEPTH); } while (0)
+    if (count_work) CRT_LAUNCH_SD(true); else CRT_LAUNCH_SD(false);
+#undef CRT_LAUNCH_SD
 #undef CRT_LAUNCH_SS
 #undef CRT_LAUNCH
     return hipGetLastError();
