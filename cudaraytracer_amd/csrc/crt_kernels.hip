@@ -208,6 +208,11 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
             if constexpr (COUNT_WORK) { if (lane == 0) { wc[0]++; wc[1] += nready; } }
             CRT_LAP(clk, 0);
             const bool active = !walking && phase != P_DONE;
+            // The shade phase reads the scene description (root box, sphere list, shading records, counts) from the kernel
+            // arguments where it needs it, like the camera: kept in scalar registers for the whole kernel it does not fit
+            // beside the walk's state and comes back through ~30 v_readlane per phase.  The walk itself only needs the
+            // node and triangle pointers (`sc`).
+            const SceneView sck = load_kernel_arg<SceneView>(offsetof(KernelArgsLayout, sc));
             bool want_scatter = false;
             Surface sf;
             sf.point = sf.normal = mk3(0.0f, 0.0f, 0.0f); sf.front_face = false; sf.prim = -1;
@@ -217,13 +222,13 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
             if (active && phase == P_HIT) {
                 float t = 0.0f;
                 int mat = 0;
-                const int code = resolve_hit(sc, p.o, p.d, tmin, FLT_MAX, hit, t, mat, stack, cnt);
+                const int code = resolve_hit(sck, p.o, p.d, tmin, FLT_MAX, hit, t, mat, stack, cnt);
                 if (code < 0) { // camera.h:68-71
                     p.color = mk3(fma1(p.attenuation.x, cam.background.x, p.color.x), fma1(p.attenuation.y, cam.background.y, p.color.y),
                                   fma1(p.attenuation.z, cam.background.z, p.color.z));
                 } else {
-                    const Shade m = sc.shades[mat]; // issued together with the primitive fetch below: one memory round trip per hit
-                    sf = surface_at<SS>(sc, code, p.o, p.d, t);
+                    const Shade m = sck.shades[mat]; // issued together with the primitive fetch below: one memory round trip per hit
+                    sf = surface_at<SS>(sck, code, p.o, p.d, t);
                     cnt.shade();
                     if (depth == 0) path_prim = sf.prim;
                     m_type = m.type; m_param = m.param;
@@ -337,7 +342,11 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                 // one Philox evaluation for both kinds of lane: stage 1 + depth for a scatter, stage 0 block 0 for a camera ray
                 u4 r;
                 r.x = r.y = r.z = r.w = 0u;
-                if (want_scatter || phase == P_NEW) r = philox4x32_10(pixel, ra.sample_offset + s_idx, want_scatter ? 1u + depth : 0u, 0u, ra.key0, ra.key1);
+                // (the keys pass through an empty asm so that the ten round keys are scalar adds here, not loop invariants of the
+                // whole kernel that live in spilled scalar registers and come back as v_readlane)
+                uint32_t key0 = ra.key0, key1 = ra.key1;
+                asm volatile("" : "+s"(key0), "+s"(key1));
+                if (want_scatter || phase == P_NEW) r = philox4x32_10(pixel, ra.sample_offset + s_idx, want_scatter ? 1u + depth : 0u, 0u, key0, key1);
                 CRT_LAP(clk, 3);
                 if (want_scatter) {
                     f3 att, no, nd;
@@ -350,7 +359,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                 CRT_LAP(clk, 4);
                 if (phase == P_NEW) {
                     const CameraPOD camk = load_kernel_arg<CameraPOD>(offsetof(KernelArgsLayout, cam));
-                    camera_ray_from(camk, i, j, pixel, ra.sample_offset + s_idx, ra.key0, ra.key1, r, p.o, p.d);
+                    camera_ray_from(camk, i, j, pixel, ra.sample_offset + s_idx, key0, key1, r, p.o, p.d);
                     p.attenuation = mk3(1.0f, 1.0f, 1.0f);
                     p.color = mk3(0.0f, 0.0f, 0.0f);
                     depth = 0;
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                 if (has_ray) {
                     cnt.ray();
                     hit.t = FLT_MAX; hit.code = -1; hit.near_tie = false;
-                    trav_begin<MODE_CLOSEST>(sc, p.o, p.d, tmin, hit, 0, 0.0f, tv, stack, cnt);
+                    trav_begin<MODE_CLOSEST>(sck, p.o, p.d, tmin, hit, 0, 0.0f, tv, stack, cnt);
                     phase = P_HIT; // what the lane does once tv.cur is CRT_BVH_NONE again (at once if the root box is missed)
                 }
             }

@@ -84,6 +84,33 @@ __global__ __launch_bounds__(64) void k(float *out, int iters, float a, float b,
     out[blockIdx.x * 64 + threadIdx.x] = s;
 }
 
+// packed fp32 (two floats per lane in a 64-bit register pair)
+#define OP_PKFMA(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %9\n"
+#define OP_PKMUL(i) "v_pk_mul_f32 %" #i ", %" #i ", %8\n"
+#define OP_PKADD(i) "v_pk_add_f32 %" #i ", %" #i ", %8\n"
+#define CHAIN8PK(OP)                                                                                                            \
+    asm volatile(OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)                                                              \
+                 : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7])            \
+                 : "v"(da), "v"(db))
+template <int KIND>
+__global__ __launch_bounds__(64) void kpk(float *out, int iters, float a, float b, int)
+{
+    double y[8];
+    for (int j = 0; j < 8; j++) y[j] = __hiloint2double(__float_as_int((float)threadIdx.x + j), __float_as_int(1.0f + j));
+    const double da = __hiloint2double(__float_as_int(a), __float_as_int(a)), db = __hiloint2double(__float_as_int(b), __float_as_int(b));
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            if (KIND == 0) CHAIN8PK(OP_PKFMA);
+            if (KIND == 1) CHAIN8PK(OP_PKMUL);
+            if (KIND == 2) CHAIN8PK(OP_PKADD);
+        }
+    }
+    float s = 0;
+    for (int j = 0; j < 8; j++) s += __int_as_float(__double2loint(y[j])) + __int_as_float(__double2hiint(y[j]));
+    out[blockIdx.x * 64 + threadIdx.x] = s;
+}
+
 typedef void (*kern_t)(float *, int, float, float, int);
 template <int K> static kern_t get() { return k<K>; }
 
@@ -92,9 +119,11 @@ int main(int argc, char **argv)
     const char *names[] = { "v_fma_f32", "v_mul_f32", "v_add_f32", "v_xor_b32", "v_add_u32", "v_mov_b32", "v_cndmask_b32", "v_cmp_lt_f32", "v_min_f32",
                             "v_max3_f32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_u32_u24", "v_mul_hi_u32_u24", "v_mad_u32_u24", "v_rcp_f32",
                             "v_sqrt_f32", "v_readlane_b32", "v_writelane_b32", "v_cvt_f32_u32", "v_lshlrev_b32", "v_div_scale_f32", "v_div_fmas_f32",
-                            "v_div_fixup_f32", "s_add_u32", "s_and_b64" };
+                            "v_div_fixup_f32", "s_add_u32", "s_and_b64", "v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32" };
     kern_t ks[] = { get<0>(), get<1>(), get<2>(), get<3>(), get<4>(), get<5>(), get<6>(), get<7>(), get<8>(), get<9>(), get<10>(), get<11>(), get<12>(),
-                    get<13>(), get<14>(), get<15>(), get<16>(), get<17>(), get<18>(), get<19>(), get<20>(), get<21>(), get<22>(), get<23>(), get<24>(), get<25>() };
+                    get<13>(), get<14>(), get<15>(), get<16>(), get<17>(), get<18>(), get<19>(), get<20>(), get<21>(), get<22>(), get<23>(), get<24>(), get<25>(),
+                    kpk<0>, kpk<1>, kpk<2> };
+    const int first = argc > 1 ? atoi(argv[1]) : 0;
     setvbuf(stdout, nullptr, _IOLBF, 0);
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, 0) != hipSuccess) { printf("no device\n"); return 1; }
@@ -104,7 +133,7 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int iters = 4000;
     const int wlist[] = { 1, 2, 5 };
-    for (int kind = 0; kind < 26; kind++) {
+    for (int kind = first; kind < 29; kind++) {
         printf("%-18s", names[kind]);
         for (int wi = 0; wi < 3; wi++) {
             const int wps = wlist[wi];
