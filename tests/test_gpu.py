@@ -374,3 +374,24 @@ def test_pipelined_tile_gather_over_rccl_single_rank(scenes, gpu_scenes, capi):
         assert np.array_equal(last.cpu().numpy().reshape(want.shape), want)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("spp,n", [(64, 64), (128, 128), (256, 32)])
+def test_many_sample_chunks(oracle, scenes, gpu_scenes, capi, spp, n):
+    """Chunk counts at and above the 64 units of a work block (a pixel's chunks then span several blocks and several waves),
+    on a ragged frame; raw sums against the oracle's per-chunk sums added in chunk order, ids and ray count exact."""
+    desc, s = gpu_scenes("cats")
+    width, height = 43, 19
+    params, cam = scenes.make_camera(width)
+    rs = oracle.RefScene(desc)
+    ocam = oracle.make_camera(params, width)
+    total = None
+    rays = 0
+    for c in range(n):
+        _, _, acc, st = rs.render(ocam, width, height, spp // n, sample_offset=c * (spp // n), want_ids=False, want_accum=True)
+        total = acc.copy() if total is None else (total + acc).astype(np.float32)
+        rays += st.rays
+    _, rids, _, _ = rs.render(ocam, width, height, 1, sample_offset=spp - 1, ids_sample=spp - 1, want_accum=True)
+    acc, ids, st = s.render(cam, width, height, spp, want_ids=True, ids_sample=spp - 1, flags=capi.OUT_ACCUM, sample_chunks=n)
+    assert st.rays == rays and np.array_equal(ids, rids)
+    assert np.array_equal(acc.reshape(total.shape), total)
