@@ -140,14 +140,14 @@ def main():
     if args.mode == "tile":
         frame = TileFrame(W, H, world, rank, device, sample_chunks=chunks, pipelined=args.frames_in_flight == 2)
 
-        def launch(want_stats=False, flags=0, timing=None):
-            return frame.render_local(scene, cam, spp, depth, seed, want_stats=want_stats, flags=flags, timing=timing)
+        def launch(want_stats=False, flags=0):
+            return frame.render_local(scene, cam, spp, depth, seed, want_stats=want_stats, flags=flags)
         finish = frame.gather_async  # two frames in flight on two streams (dist.py): drain() completes the last ones
     else:
         frame = SampleFrame(W, H, spp, world, rank, device, sample_chunks=chunks, pipelined=args.frames_in_flight == 2)
 
-        def launch(want_stats=False, flags=0, timing=None):
-            return frame.render_local(scene, cam, depth, seed, want_stats=want_stats, flags=flags, timing=timing)
+        def launch(want_stats=False, flags=0):
+            return frame.render_local(scene, cam, depth, seed, want_stats=want_stats, flags=flags)
         finish = frame.reduce_async
 
     def barrier():
@@ -210,7 +210,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d %dspp depth %d (models/%s + ground + emissive sphere, seed %d)" %
                        (args.workload, W, H, spp, depth, {"cats": "cats.obj", "random_spheres": "no mesh"}.get(builder, "cat.obj"), seed),
-                       "partition": "%s x%d" % (args.mode, world), "frames_in_flight": frame.slots.n, "sample_chunks": chunks if args.mode == "tile" else frame.sample_chunks, "triangles": info.num_triangles, "bvh_nodes": info.num_nodes,
+                       "partition": "%s x%d" % (args.mode, world), "frames_in_flight": frame.slots.in_flight, "sample_chunks": chunks if args.mode == "tile" else frame.sample_chunks, "triangles": info.num_triangles, "bvh_nodes": info.num_nodes,
                        "rays_per_frame": int(rays_frame), "device_cus": cus},
             "roofline": {"bound": "valu", "achieved": ops / ksec / 1e12, "peak": valu_peak, "unit": "Tlane-op/s",
                          "frac": ops / ksec / 1e12 / valu_peak, "traffic": traffic,

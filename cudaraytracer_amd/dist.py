@@ -29,66 +29,76 @@ def _device_finalize(accum, width, height, total_spp, frame):
 
 
 class _Slots:
-    """Frames in flight.  Not pipelined: one slot on the caller's current stream.  Pipelined: two slots, each with its own
-    HIP stream and buffers; frame k uses slot k % 2, so frame k + 1 is launched while frame k is still running.  The render
-    kernel is persistent and fills every wave slot of the GPU, so the younger frame's workgroups only get in as the older
-    frame's waves drain: the ramp-down of one frame is covered by the ramp-up of the next, and so are its collective
-    and its epilogue.  (crt_render keeps one scratch set per stream, which is what allows the overlap.)"""
+    """Frames in flight.  Not pipelined: one buffer set, everything on the caller's current stream.  Pipelined: consecutive
+    frames alternate between two render streams, and everything that follows a frame's render -- the wait for its collective
+    and its epilogue -- runs on a third stream, over four buffer sets, so that no render ever waits for a collective.
+
+    Why: the render kernel is persistent and fills every wave slot of the GPU, so the younger frame's workgroups only get in
+    as the older frame's waves drain: the ramp-down of one frame is covered by the ramp-up of the next.  The collective's
+    own kernels need wave slots too and only find them when a render drains; if the next render on that stream had to wait
+    for the collective (as it would with two buffer sets), that overlap would be lost on every rank.  (crt_render keeps one
+    scratch set per stream, which is what allows two renders to overlap.)"""
 
     def __init__(self, device, pipelined):
         self.device = torch.device(device)
         self.gpu = self.device.type == "cuda"
-        self.n = 2 if pipelined else 1
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.n)] if (self.gpu and pipelined) else [None] * self.n
-        self.k = 0                      # frames started
-        self.pending = [None] * self.n  # per slot: what finishes the frame that used it last
+        self.pipelined = bool(pipelined)
+        self.n = 4 if pipelined else 1           # buffer sets
+        self.in_flight = 2 if pipelined else 1   # render streams
+        on_gpu = self.gpu and pipelined
+        self.render_streams = [torch.cuda.Stream(self.device) for _ in range(2)] if on_gpu else [None]
+        self.epilogue = torch.cuda.Stream(self.device) if on_gpu else None
+        self.done = [None] * self.n  # per buffer set: event after the last thing that used it
+        self.k = 0                   # frames started
 
     @property
     def slot(self):
         return self.k % self.n
 
-    def on(self, slot):
-        """Context: the slot's stream is torch's current stream."""
-        st = self.streams[slot]
-        return torch.cuda.stream(st) if st is not None else contextlib.nullcontext()
+    def render_stream(self):
+        return self.render_streams[self.k % len(self.render_streams)]
 
-    def begin(self, finish):
-        """Start a frame on the current slot: finish the frame that used the slot before; returns the slot."""
-        slot = self.slot
-        st = self.streams[slot]
+    @staticmethod
+    def on(stream):
+        """Context: `stream` is torch's current stream (None: leave it alone)."""
+        return torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()
+
+    def begin(self):
+        """Start frame k: returns (buffer set, render stream).  The render stream first waits for what the caller enqueued so
+        far (uploads, ...) and for the last user of the buffer set (frame k - 4's epilogue)."""
+        slot, st = self.slot, self.render_stream()
         if st is not None:
-            st.wait_stream(torch.cuda.current_stream(self.device))  # what the caller enqueued so far (uploads, ...) comes first
-        self.finish_slot(slot, finish)
-        return slot
+            st.wait_stream(torch.cuda.current_stream(self.device))
+            if self.done[slot] is not None:
+                st.wait_event(self.done[slot])
+        return slot, st
 
-    def finish_slot(self, slot, finish):
-        if self.pending[slot] is not None:
-            pending, self.pending[slot] = self.pending[slot], None
-            with self.on(slot):
-                finish(pending, slot)
+    def mark_done(self, slot, stream):
+        if stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self.done[slot] = ev
 
-    def drain(self, finish):
-        """Finish every frame in flight, oldest first; the caller's current stream then waits for the slots' streams."""
-        for d in range(self.n):
-            self.finish_slot((self.k + d) % self.n, finish)
-        for st in self.streams:
-            if st is not None:
-                torch.cuda.current_stream(self.device).wait_stream(st)
+    def drain(self):
+        """The caller's current stream waits for everything in flight."""
+        if self.gpu and self.pipelined:
+            cur = torch.cuda.current_stream(self.device)
+            for st in self.render_streams + [self.epilogue]:
+                cur.wait_stream(st)
 
-    def stream_handle(self, slot):
+    def handle(self, stream):
         if not self.gpu:
             return None
-        st = self.streams[slot]
-        return (st if st is not None else torch.cuda.current_stream(self.device)).cuda_stream
+        return (stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
 
 
 class TileFrame:
     """Tile-partitioned frame.  Synchronous use: render_local(); gather() -> self.frame (on every rank).
 
-    Pipelined use (pipelined=True): render_local(); gather_async(); ... ; drain().  Two frames are in flight on two HIP
-    streams with their own buffers: gather_async() starts the frame's all-gather behind its render, the frame is
-    finished (wait for the collective + de-interleave, on its stream) when its slot is used again or by drain().
-    Every frame is assembled on every rank exactly as gather() would; self.frame is the youngest finished frame."""
+    Pipelined use (pipelined=True): render_local(); gather_async(); ... ; drain().  gather_async() enqueues the frame's
+    all-gather behind its render and its de-interleave behind that, on the epilogue stream (see _Slots); nothing waits on
+    the host (nccl).  Every frame is assembled on every rank exactly as gather() would; self.frame is the frame submitted
+    last, complete once drain() has returned (for the caller's current stream) or on `self.slots.epilogue`."""
 
     def __init__(self, width, height, world, rank, device, untile_fn=None, sample_chunks=0, pipelined=False, force_collective=False):
         self.width, self.height, self.world, self.rank = width, height, world, rank
@@ -102,7 +112,8 @@ class TileFrame:
         self._frame = [torch.zeros(height * width * 3, dtype=torch.float32, device=device) for _ in range(nbuf)]
         self._local = [torch.zeros(self.n, dtype=torch.float32, device=device) for _ in range(nbuf)] if self.collective else None
         self._all = [torch.zeros(self.n * world, dtype=torch.float32, device=device) for _ in range(nbuf)] if self.collective else None
-        self._newest = 0  # slot of the youngest finished (or, without a collective, launched) frame
+        self._newest = 0      # buffer set of the frame submitted last
+        self._current = None  # (buffer set, render stream) of the frame between render_local() and gather_async()
         self.untile_fn = untile_fn or _device_untile
 
     @property
@@ -114,39 +125,33 @@ class TileFrame:
         """This rank's compact tile list (the buffer the next render_local() fills)."""
         return self._local[self.slots.slot] if self._local else None
 
-    def _finish(self, work, slot):
-        if work is not True:
-            work.wait()  # the slot's stream waits for the collective; the host does not (nccl)
-            self.untile_fn(self._all[slot], self.width, self.height, self.world, self._frame[slot])
-        self._newest = slot
-
-    def render_local(self, scene, cam, spp, max_depth, seed, want_stats=False, flags=0, timing=None):
-        """Launch this rank's tiles (asynchronous unless want_stats).  timing = (start, end) torch events recorded around
-        the launch on the stream it runs on."""
-        slot = self.slots.begin(self._finish)
-        stream = self.slots.stream_handle(slot)
-        with self.slots.on(slot):
-            if timing:
-                timing[0].record()
+    def render_local(self, scene, cam, spp, max_depth, seed, want_stats=False, flags=0):
+        """Launch this rank's tiles (asynchronous unless want_stats)."""
+        slot, st = self.slots.begin()
+        self._current = (slot, st)
+        with self.slots.on(st):
             if not self.collective:
-                st = scene.render(cam, self.width, self.height, spp, max_depth=max_depth, seed=seed, out_rgb=self._frame[slot].data_ptr(),
-                                  want_stats=want_stats, stream=stream, flags=flags, sample_chunks=self.sample_chunks)[2]
-            else:
-                st = scene.render(cam, self.width, self.height, spp, max_depth=max_depth, seed=seed, tile_rank=self.rank, tile_ranks=self.world,
-                                  flags=flags | capi.OUT_COMPACT, out_rgb=self._local[slot].data_ptr(), want_stats=want_stats, stream=stream,
-                                  sample_chunks=self.sample_chunks)[2]
-            if timing:
-                timing[1].record()
-        return st
+                return scene.render(cam, self.width, self.height, spp, max_depth=max_depth, seed=seed, out_rgb=self._frame[slot].data_ptr(),
+                                    want_stats=want_stats, stream=self.slots.handle(st), flags=flags, sample_chunks=self.sample_chunks)[2]
+            return scene.render(cam, self.width, self.height, spp, max_depth=max_depth, seed=seed, tile_rank=self.rank, tile_ranks=self.world,
+                                flags=flags | capi.OUT_COMPACT, out_rgb=self._local[slot].data_ptr(), want_stats=want_stats,
+                                stream=self.slots.handle(st), sample_chunks=self.sample_chunks)[2]
 
     def gather_async(self):
-        """Start the all-gather of the frame just rendered (behind its render, on its slot's stream)."""
-        slot = self.slots.slot
+        """Enqueue the all-gather of the frame just rendered and, behind it, the de-interleave into its frame buffer."""
+        slot, st = self._current if self._current is not None else (self.slots.slot, self.slots.render_stream())
+        self._current = None
         if self.collective:
-            with self.slots.on(slot):
-                self.slots.pending[slot] = dist.all_gather_into_tensor(self._all[slot], self._local[slot], async_op=True)
+            with self.slots.on(st):  # the collective's stream waits for the render stream up to here
+                work = dist.all_gather_into_tensor(self._all[slot], self._local[slot], async_op=True)
+            ep = self.slots.epilogue
+            with self.slots.on(ep):
+                work.wait()          # the epilogue stream waits for the collective; the host does not (nccl)
+                self.untile_fn(self._all[slot], self.width, self.height, self.world, self._frame[slot])
+            self.slots.mark_done(slot, ep)
         else:
-            self.slots.pending[slot] = True
+            self.slots.mark_done(slot, st)
+        self._newest = slot
         self.slots.k += 1
 
     def gather(self):
@@ -154,14 +159,14 @@ class TileFrame:
         return self.drain()
 
     def drain(self):
-        """Finish the frames in flight; self.frame is then the last frame rendered, complete on the caller's stream."""
-        self.slots.drain(self._finish)
+        """Everything in flight completes before what the caller enqueues next; returns the frame submitted last."""
+        self.slots.drain()
         return self.frame
 
 
 class SampleFrame:
     """Sample-partitioned frame: render_local(); reduce() -> self.frame (valid on rank 0).
-    Pipelined (two frames in flight, see TileFrame): render_local(); reduce_async(); ...; drain()."""
+    Pipelined (see TileFrame): render_local(); reduce_async(); ...; drain()."""
 
     def __init__(self, width, height, total_spp, world, rank, device, finalize_fn=None, sample_chunks=0, pipelined=False):
         if total_spp % world:
@@ -176,6 +181,7 @@ class SampleFrame:
         self._accum = [torch.zeros(height * width * 3, dtype=torch.float32, device=device) for _ in range(nbuf)]
         self._frame = [torch.zeros(height * width * 3, dtype=torch.float32, device=device) for _ in range(nbuf if rank == 0 else 1)]
         self._newest = 0
+        self._current = None
         self.finalize_fn = finalize_fn or _device_finalize
 
     @property
@@ -187,33 +193,31 @@ class SampleFrame:
         """Raw float sums of this rank's samples (the buffer the next render_local() fills)."""
         return self._accum[self.slots.slot]
 
-    def _finish(self, work, slot):
-        if work is not True:
-            work.wait()
-        if self.rank == 0:
-            self.finalize_fn(self._accum[slot], self.width, self.height, self.total_spp, self._frame[slot])
-            self._newest = slot
-
-    def render_local(self, scene, cam, max_depth, seed, want_stats=False, timing=None, flags=0):
-        slot = self.slots.begin(self._finish)
-        stream = self.slots.stream_handle(slot)
-        with self.slots.on(slot):
-            if timing:
-                timing[0].record()
-            st = scene.render(cam, self.width, self.height, self.spp_local, max_depth=max_depth, seed=seed, sample_offset=self.rank * self.spp_local,
-                              flags=flags | capi.OUT_ACCUM, out_rgb=self._accum[slot].data_ptr(), want_stats=want_stats, stream=stream,
-                              sample_chunks=self.sample_chunks)[2]
-            if timing:
-                timing[1].record()
-        return st
+    def render_local(self, scene, cam, max_depth, seed, want_stats=False, flags=0):
+        slot, st = self.slots.begin()
+        self._current = (slot, st)
+        with self.slots.on(st):
+            return scene.render(cam, self.width, self.height, self.spp_local, max_depth=max_depth, seed=seed, sample_offset=self.rank * self.spp_local,
+                                flags=flags | capi.OUT_ACCUM, out_rgb=self._accum[slot].data_ptr(), want_stats=want_stats,
+                                stream=self.slots.handle(st), sample_chunks=self.sample_chunks)[2]
 
     def reduce_async(self):
-        slot = self.slots.slot
+        slot, st = self._current if self._current is not None else (self.slots.slot, self.slots.render_stream())
+        self._current = None
+        ep = self.slots.epilogue if self.slots.epilogue is not None else st
+        work = None
         if self.world > 1:
-            with self.slots.on(slot):
-                self.slots.pending[slot] = dist.reduce(self._accum[slot], dst=0, op=dist.ReduceOp.SUM, async_op=True)
-        else:
-            self.slots.pending[slot] = True
+            with self.slots.on(st):
+                work = dist.reduce(self._accum[slot], dst=0, op=dist.ReduceOp.SUM, async_op=True)
+        with self.slots.on(ep):
+            if self.slots.epilogue is not None and st is not None:
+                ep.wait_stream(st)  # (with a collective its wait below implies this)
+            if work is not None:
+                work.wait()
+            if self.rank == 0:
+                self.finalize_fn(self._accum[slot], self.width, self.height, self.total_spp, self._frame[slot])
+        self.slots.mark_done(slot, ep)
+        self._newest = slot
         self.slots.k += 1
 
     def reduce(self):
@@ -221,5 +225,5 @@ class SampleFrame:
         return self.drain()
 
     def drain(self):
-        self.slots.drain(self._finish)
+        self.slots.drain()
         return self.frame

@@ -63,12 +63,12 @@ def _worker(rank, world, port, mode, outdir):
     first = None
     if mode.startswith("tile"):
         f = TileFrame(W, H, world, rank, torch.device("cpu"), untile_fn=untile, pipelined=mode.endswith("pipelined"))
-        if mode.endswith("pipelined"):   # three frames over two slots: starting frame 2 finishes frame 0 (seed 7)
-            for seed in (7, 11, 1984):
+        if mode.endswith("pipelined"):   # six frames over the four buffer sets; the first one (seed 7) is kept for the check
+            for seed in (7, 11, 13, 17, 19, 1984):
                 f.render_local(scene, cam, SPP, 10, seed)
-                if seed == 1984:
-                    first = f.frame.clone()
                 f.gather_async()
+                if seed == 7:
+                    first = f.frame.clone()   # (gloo: the collective has completed on return)
             frame = f.drain()
         else:
             f.render_local(scene, cam, SPP, 10, 1984)
@@ -76,11 +76,11 @@ def _worker(rank, world, port, mode, outdir):
     else:
         f = SampleFrame(W, H, SPP, world, rank, torch.device("cpu"), finalize_fn=finalize, pipelined=mode.endswith("pipelined"))
         if mode.endswith("pipelined"):
-            for seed in (7, 11, 1984):
+            for seed in (7, 11, 13, 17, 19, 1984):
                 f.render_local(scene, cam, 10, seed)
-                if seed == 1984:
-                    first = f.frame.clone()
                 f.reduce_async()
+                if seed == 7:
+                    first = f.frame.clone()
             frame = f.drain()
         else:
             f.render_local(scene, cam, 10, 1984)
@@ -111,7 +111,7 @@ def test_frame_assembly_over_gloo(oracle, scenes, hostsim, tmp_path, mode, world
     else:                        # sample split: float sum order differs -> within 2 ulp of the gamma-encoded value
         got = np.load(tmp_path / ("frame_%s_0.npy" % mode))
         assert np.allclose(got, fb, rtol=3e-7, atol=1e-7)
-    if mode.endswith("pipelined"):   # the frame that was in flight while the second one was produced (seed 7)
+    if mode.endswith("pipelined"):   # the first of the six frames (seed 7)
         fb7 = rs.render(oracle.make_camera(params, W), W, H, SPP, seed=7)[0]
         if mode.startswith("tile"):
             for r in range(world):

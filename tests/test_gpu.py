@@ -334,7 +334,7 @@ def test_randomised_configurations_against_oracle(oracle, scenes, gpu_scenes, ca
 
 def test_pipelined_tile_gather_over_rccl_single_rank(scenes, gpu_scenes, capi):
     """dist.TileFrame's pipelined path on the real backend: a 1-rank nccl (= RCCL) group, three frames with two all-gathers
-    in flight over double buffers; every frame that comes out equals the direct render of its seed, bit for bit."""
+    in flight; every frame that comes out equals the direct render of its seed, bit for bit."""
     import socket
     import torch
     import torch.distributed as dist
@@ -350,21 +350,19 @@ def test_pipelined_tile_gather_over_rccl_single_rank(scenes, gpu_scenes, capi):
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
     try:
         f = TileFrame(W, H, 1, 0, dev, sample_chunks=2, pipelined=True, force_collective=True)
-        seeds, got = (3, 5, 7, 1984), []
-        for k, seed in enumerate(seeds):
-            f.render_local(s, cam, spp, 10, seed)   # from the third frame on this finishes the frame two before it
-            if k >= 2:   # f.frame was written on its slot's stream: read it there (drain() is what hands frames to the caller's stream)
-                with torch.cuda.stream(f.slots.streams[f._newest]):
-                    got.append(f.frame.clone())
+        seeds, got = (3, 5, 7, 11, 13, 1984), []   # six frames over four buffer sets: two sets are used twice
+        for seed in seeds:
+            f.render_local(s, cam, spp, 10, seed)
             f.gather_async()
-        f.drain()
-        got.append(f._frame[(len(seeds) - 2) % 2].clone())
-        got.append(f.frame.clone())
+            with torch.cuda.stream(f.slots.epilogue):   # the frame is complete on the epilogue stream (drain() hands it to the caller's)
+                got.append(f.frame.clone())
+        last = f.drain().clone()
         torch.cuda.synchronize()
         for seed, frame in zip(seeds, got):
             want = s.render(cam, W, H, spp, seed=seed, sample_chunks=2)[0]
             assert np.array_equal(frame.cpu().numpy().reshape(want.shape), want), seed
-        # and without a collective: two frames in flight straight into the two frame buffers
+        assert np.array_equal(last.cpu().numpy().reshape(want.shape), want)
+        # and without a collective: two frames in flight straight into the frame buffers
         g = TileFrame(W, H, 1, 0, dev, sample_chunks=2, pipelined=True)
         for seed in seeds:
             g.render_local(s, cam, spp, 10, seed)
