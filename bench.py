@@ -123,12 +123,7 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # the collectives' kernels have to find wave slots beside a persistent render kernel: give their stream priority
-        try:
-            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-            dist.init_process_group(backend="nccl", device_id=device, pg_options=opts)
-        except (AttributeError, TypeError):
-            dist.init_process_group(backend="nccl", device_id=device)
+        dist.init_process_group(backend="nccl", device_id=device)
 
     builder, W, H, spp, depth, cam_over = WORKLOADS[args.workload]
     if args.spp:

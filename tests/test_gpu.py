@@ -347,8 +347,7 @@ def test_pipelined_tile_gather_over_rccl_single_rank(scenes, gpu_scenes, capi):
     port = sock.getsockname()[1]
     sock.close()
     dev = torch.device("cuda", 0)
-    opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)   # as bench.py does
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev, pg_options=opts)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
     try:
         f = TileFrame(W, H, 1, 0, dev, sample_chunks=2, pipelined=True, force_collective=True)
         seeds, got = (3, 5, 7, 11, 13, 1984), []   # six frames over four buffer sets: two sets are used twice
