@@ -102,6 +102,37 @@ __device__ __forceinline__ T load_kernel_arg(size_t offset)
     return r.v;
 }
 
+// Node records: the first `ncached` nodes (breadth-first numbering = the top of the tree) from the workgroup's LDS copy,
+// the others from device memory.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const v4f *lds_q4_ptr; // keeps the LDS copy on ds_read (a generic pointer would load via flat_)
+__device__ __forceinline__ q4 to_q4(v4f v) { q4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+struct CachedNodes {
+    const q4 *global;
+    lds_q4_ptr lds;
+    int ncached;
+    __device__ __forceinline__ void fetch(int cur, q4 &n0, q4 &n1, q4 &n2, q4 &n3) const
+    {
+        if (cur < ncached) {
+            lds_q4_ptr n = lds + 4u * (uint32_t)cur;
+            n0 = to_q4(n[0]); n1 = to_q4(n[1]); n2 = to_q4(n[2]); n3 = to_q4(n[3]);
+        } else {
+            const q4 *n = global + 4u * (uint32_t)cur;
+            n0 = n[0]; n1 = n[1]; n2 = n[2]; n3 = n[3];
+        }
+    }
+};
+
+
+struct LdsNodes { // the LDS copy only (the caller has checked cur < ncached)
+    lds_q4_ptr lds;
+    __device__ __forceinline__ void fetch(int cur, q4 &n0, q4 &n1, q4 &n2, q4 &n3) const
+    {
+        lds_q4_ptr n = lds + 4u * (uint32_t)cur;
+        n0 = to_q4(n[0]); n1 = to_q4(n[1]); n2 = to_q4(n[2]); n3 = to_q4(n[3]);
+    }
+};
+
 // Section clock of the instrumented kernel (CRT_COUNT_WORK): shader-clock ticks a wave spends in each part of the loop
 template <bool ON>
 struct SectionClock {
@@ -156,6 +187,12 @@ static_assert(CRT_WORK_STRIPES == 64u, "the order in which a wave visits the blo
 #ifndef CRT_NODE_STEPS_PER_VOTE
 #define CRT_NODE_STEPS_PER_VOTE 2
 #endif
+#ifndef CRT_NODE_CACHE_NODES
+#define CRT_NODE_CACHE_NODES 192 // 4 waves x 4.6 KB of stack + 12 KB of nodes = 30 KB per workgroup: five per CU = the same 20 waves
+#endif
+#ifndef CRT_LDS_STEPS_PER_VOTE
+#define CRT_LDS_STEPS_PER_VOTE 3 // node steps per vote when the nodes come from the LDS copy
+#endif
 #ifndef CRT_WAVES_PER_EU
 #define CRT_WAVES_PER_EU 5 // 512 VGPRs / 5 waves -> 96 registers per lane; the few spills this forces sit on the rare tie path
 #endif
@@ -164,12 +201,28 @@ static_assert(CRT_WORK_STRIPES == 64u, "the order in which a wave visits the blo
 #else
 #define CRT_OCCUPANCY_ATTR
 #endif
-template <bool COUNT_WORK, int SD, bool SS>
-__global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
+template <bool COUNT_WORK, int SD, bool SS, int W, int NC>
+__global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
                                                                        int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
-    __shared__ int lds_stack[(SD + 2) * 64]; // SD = 16 when the BVH is at most 16 levels deep: 20 instead of 18 waves per CU
-    const uint32_t lane = threadIdx.x;
+    // W waves per workgroup, each on its own; with NC > 0 they share an LDS copy of the first NC nodes (breadth-first
+    // numbering: the top of the tree).  The kernel is limited by L1 accesses as much as by VALU issue (one more dwordx4
+    // load per node step costs 13 % of the frame), and 77 % of the node visits of the headline scene go to the first 256
+    // nodes: those become ds_read_b128.  5 waves x 4.6 KB of stack + 16 KB of nodes = 39 KB: four workgroups per CU, the
+    // same 20 waves as with one wave per workgroup.
+    __shared__ int lds_stack_all[W][(SD + 2) * 64]; // SD = 16 when the BVH is at most 16 levels deep
+    __shared__ v4f lds_nodes[NC > 0 ? 4 * NC : 1];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    int *lds_stack = lds_stack_all[wave];
+    CachedNodes node_src;
+    node_src.global = sc.nodes; node_src.lds = (lds_q4_ptr)lds_nodes; node_src.ncached = NC > 0 ? min((int)sc.nnodes, NC) : 0;
+    if (NC > 0) {
+        const v4f *g = reinterpret_cast<const v4f *>(sc.nodes);
+        for (uint32_t k = threadIdx.x; k < 4u * (uint32_t)node_src.ncached; k += 64u * W) lds_nodes[k] = g[k];
+        __syncthreads(); // the only workgroup barrier: from here on the waves do not meet again
+    }
+    // home counter of this wave: index mod 8 = workgroup mod 8 = the XCD the workgroup runs on (round robin)
+    const uint32_t home = (blockIdx.x & 7u) | ((((blockIdx.x >> 3) * W + wave) & 7u) << 3);
     unsigned int *work = reinterpret_cast<unsigned int *>(counters + 32); // block counters, 64 dwords apart (crt_kernels.h)
     const uint32_t NO_PIXEL = 0xFFFFFFFFu;
     const float tmin = 0.001f; // camera.h:68
@@ -183,7 +236,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
     int primary = -1, path_prim = -1;
     int phase = P_FETCH;
     uint32_t blk_next = 0, blk_end = 0; // the wave's block of work units [blk_next, blk_end) (wave-uniform)
-    uint32_t stripe = blockIdx.x % CRT_WORK_STRIPES, stripes_left = CRT_WORK_STRIPES; // counter in use, counters not yet seen empty
+    uint32_t stripe = home, stripes_left = CRT_WORK_STRIPES; // counter in use, counters not yet seen empty
     uint32_t s_idx = 0, s_end = 0, depth = 0; // samples [s_idx, s_end) of the pixel are still to do (s_end = spp without chunks)
     Path p;
     p.o = p.d = p.attenuation = p.color = mk3(0.0f, 0.0f, 0.0f);
@@ -293,7 +346,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                         // else the next counter: first the ones with the same index mod 8 (workgroups go round robin over the 8
                         // XCDs, so those are the bands this XCD's L2 already serves), then the next residue
                         stripes_left--;
-                        const uint32_t seen = CRT_WORK_STRIPES - stripes_left, s0 = blockIdx.x % CRT_WORK_STRIPES;
+                        const uint32_t seen = CRT_WORK_STRIPES - stripes_left, s0 = home;
                         stripe = ((((s0 >> 3) + seen) & 7u) << 3) | (((s0 & 7u) + (seen >> 3)) & 7u);
                     }
                 }
@@ -384,15 +437,38 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void render_kernel(SceneView
                 const int nw = n_inner + n_leaf;
                 if (nw == 0 || alive - nw >= threshold) break;
                 CRT_LAP(clk, 0);
-                if (n_inner >= n_leaf) {
-                    if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_inner; } }
-                    if (inner) trav_inner(sc, tv, stack, cnt);
+                // With the LDS copy of the top of the tree a node step is either all-LDS or all-global: a vector memory
+                // instruction occupies the CU's one address unit for 16 cycles whatever the number of active lanes, so a
+                // step that mixes both sources pays for both.
+                bool in_lds = false;
+                int n_lds = 0;
+                if constexpr (NC > 0) {
+                    in_lds = inner && tv.cur < node_src.ncached;
+                    n_lds = popc64(__ballot(in_lds));
+                }
+                const int n_glob = n_inner - n_lds;
+                if (NC > 0 && n_lds >= n_glob && n_lds >= n_leaf) {
+                    if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_lds; } }
+                    LdsNodes top;
+                    top.lds = node_src.lds;
+                    if (in_lds) trav_inner_from(top, tv, stack, cnt);
+#pragma unroll
+                    for (int k = 1; k < CRT_LDS_STEPS_PER_VOTE; k++) {
+                        const bool again = in_lds && is_inner(tv.cur) && tv.cur < node_src.ncached;
+                        if constexpr (COUNT_WORK) { const int na = popc64(__ballot(again)); if (lane == 0) { wc[4]++; wc[5] += na; } }
+                        if (again) trav_inner_from(top, tv, stack, cnt);
+                    }
+                    CRT_LAP(clk, 7);
+                } else if (n_glob >= n_leaf) {
+                    const bool mine = inner && !in_lds;
+                    if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_glob; } }
+                    if (mine) trav_inner(sc, tv, stack, cnt);
                     // more node steps on the same vote: descents come in runs, and the vote costs half a step in scalar work
 #pragma unroll
                     for (int k = 1; k < CRT_NODE_STEPS_PER_VOTE; k++) {
-                        const bool again = is_inner(tv.cur);
-                        if constexpr (COUNT_WORK) { const int na = popc64(__ballot(inner && again)); if (lane == 0) { wc[4]++; wc[5] += na; } }
-                        if (inner && again) trav_inner(sc, tv, stack, cnt);
+                        const bool again = mine && is_inner(tv.cur) && (NC == 0 || tv.cur >= node_src.ncached);
+                        if constexpr (COUNT_WORK) { const int na = popc64(__ballot(again)); if (lane == 0) { wc[4]++; wc[5] += na; } }
+                        if (again) trav_inner(sc, tv, stack, cnt);
                     }
                     CRT_LAP(clk, 7);
                 } else {
@@ -507,27 +583,6 @@ __device__ __forceinline__ int ray_start(const SceneView &sc, Pool<P> &pool, int
     pool.set(CF_PACK, c, pack_run);
     return DEST_SHADE;
 }
-
-// Node records: the first `ncached` nodes (breadth-first numbering = the top of the tree) from the workgroup's LDS copy,
-// the others from device memory.
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) const v4f *lds_q4_ptr; // keeps the LDS copy on ds_read (a generic pointer would load via flat_)
-__device__ __forceinline__ q4 to_q4(v4f v) { q4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
-struct CachedNodes {
-    const q4 *global;
-    lds_q4_ptr lds;
-    int ncached;
-    __device__ __forceinline__ void fetch(int cur, q4 &n0, q4 &n1, q4 &n2, q4 &n3) const
-    {
-        if (cur < ncached) {
-            lds_q4_ptr n = lds + 4u * (uint32_t)cur;
-            n0 = to_q4(n[0]); n1 = to_q4(n[1]); n2 = to_q4(n[2]); n3 = to_q4(n[3]);
-        } else {
-            const q4 *n = global + 4u * (uint32_t)cur;
-            n0 = n[0]; n1 = n[1]; n2 = n[2]; n3 = n[3];
-        }
-    }
-};
 
 // LDS traffic between lanes of one wave needs no hardware barrier (a wave's LDS operations complete in order); this
 // only keeps the compiler from moving them across the hand-over points.
@@ -886,7 +941,8 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     // allow) or 32 (8.7 KB: 18 waves per CU)
     const bool ss = sc.sphere_slots != 0;
     const int levels = ra.bvh_depth <= 16 ? 16 : ra.bvh_depth <= 24 ? 24 : CRT_STACK_DEPTH;
-#define CRT_LAUNCH(CW, SD, SS) hipLaunchKernelGGL((render_kernel<CW, SD, SS>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters)
+#define CRT_LAUNCH(CW, SD, SS) do { if (a.node_cache && SD == 16) hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, CRT_NODE_CACHE_NODES>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters); \
+                                     else hipLaunchKernelGGL((render_kernel<CW, SD, SS, 1, 0>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters); } while (0)
 #define CRT_LAUNCH_SS(CW, SD) do { if (ss) CRT_LAUNCH(CW, SD, true); else CRT_LAUNCH(CW, SD, false); } while (0)
 #define CRT_LAUNCH_SD(CW) do { if (levels == 16) CRT_LAUNCH_SS(CW, 16); else if (levels == 24) CRT_LAUNCH_SS(CW, 24); else CRT_LAUNCH_SS(CW, CRT_STACK_DEPTH); } while (0)
     if (count_work) CRT_LAUNCH_SD(true); else CRT_LAUNCH_SD(false);
