@@ -265,7 +265,11 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
             // arguments where it needs it, like the camera: kept in scalar registers for the whole kernel it does not fit
             // beside the walk's state and comes back through ~30 v_readlane per phase.  The walk itself only needs the
             // node and triangle pointers (`sc`).
-            const SceneView sck = load_kernel_arg<SceneView>(offsetof(KernelArgsLayout, sc));
+            SceneView sck = load_kernel_arg<SceneView>(offsetof(KernelArgsLayout, sc));
+            // (pointers rebuilt from raw argument words are generic to the compiler, i.e. flat_load: the node and triangle
+            // pointers are the walk's own, and the shade phase reads spheres / shading records / triangles through
+            // load_uniform / load_global)
+            sck.nodes = sc.nodes; sck.tris = sc.tris;
             bool want_scatter = false;
             Surface sf;
             sf.point = sf.normal = mk3(0.0f, 0.0f, 0.0f); sf.front_face = false; sf.prim = -1;
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                     p.color = mk3(fma1(p.attenuation.x, cam.background.x, p.color.x), fma1(p.attenuation.y, cam.background.y, p.color.y),
                                   fma1(p.attenuation.z, cam.background.z, p.color.z));
                 } else {
-                    const Shade m = sck.shades[mat]; // issued together with the primitive fetch below: one memory round trip per hit
+                    const Shade m = load_global(sck.shades, (size_t)mat); // issued together with the primitive fetch below: one memory round trip per hit
                     sf = surface_at<SS>(sck, code, p.o, p.d, t);
                     cnt.shade();
                     if (depth == 0) path_prim = sf.prim;

@@ -113,6 +113,33 @@ CRT_HD float fast_rcp(float x)
 #endif
 }
 
+// element k of a read-only device array, k the same in every lane: on the device through the constant address space, so
+// that it is a scalar load (one request through the scalar cache instead of a vector load that keeps the CU's address
+// unit busy for 16 cycles per 16 bytes)
+template <class T>
+CRT_HD T load_uniform(const T *p, uint32_t k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(4))) const T *constant_ptr;
+    return *((constant_ptr)(uintptr_t)p + k);
+#else
+    return p[k];
+#endif
+}
+
+// element k of a device array through the global address space (a pointer rebuilt from raw kernel-argument words is generic
+// to the compiler, and generic means flat_load)
+template <class T>
+CRT_HD T load_global(const T *p, size_t k)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef __attribute__((address_space(1))) const T *global_ptr;
+    return *((global_ptr)(uintptr_t)p + k);
+#else
+    return p[k];
+#endif
+}
+
 CRT_HD bool is_inner(int ref) { return (unsigned)ref < (unsigned)CRT_BVH_NONE; }
 
 // Spheres: a short flat list (ground + light in the reference scenes, scene.h:164-165), tested before the BVH.
@@ -122,7 +149,7 @@ template <int MODE, class Counters>
 CRT_HD void trav_spheres(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Counters &cnt)
 {
     for (uint32_t k = 0; k < sc.nspheres; k++) {
-        const Sphere sp = sc.spheres[k];
+        const Sphere sp = load_uniform(sc.spheres, k);
         float t;
         cnt.sphere();
         if (sphere_t(mk3(sp.cx, sp.cy, sp.cz), sp.radius, o, d, tmin, t)) offer<MODE>(s, t, (int)(sc.ntris + k), sp.mat, sp.rank, after_rank, t_hi);
@@ -307,20 +334,20 @@ CRT_HD Surface surface_at(const SceneView &sc, int code, f3 o, f3 d, float t)
     Surface r;
     r.point = axpy(t, d, o);
     if ((uint32_t)code < sc.ntris) {
-        const q4 *tp = sc.tris + 3 * (size_t)code;
-        const q4 ta = tp[0], tb = tp[1], tc = tp[2];
+        const size_t k = 3 * (size_t)code;
+        const q4 ta = load_global(sc.tris, k), tb = load_global(sc.tris, k + 1), tc = load_global(sc.tris, k + 2);
         const f3 a = mk3(ta.x, ta.y, ta.z);
         const f3 n = normalize(cross(mk3(tb.x, tb.y, tb.z) - a, mk3(tc.x, tc.y, tc.z) - a));
         r.normal = face_normal(d, n, r.front_face);
         r.prim = f2i(ta.w);
     } else if (SPHERE_SLOTS && (code & CRT_SPHERE_SLOT)) {
-        const q4 *tp = sc.tris + 3 * (size_t)(code & ~CRT_SPHERE_SLOT);
-        const q4 ta = tp[0], tb = tp[1];
+        const size_t k = 3 * (size_t)(code & ~CRT_SPHERE_SLOT);
+        const q4 ta = load_global(sc.tris, k), tb = load_global(sc.tris, k + 1);
         const f3 outward = div3(r.point - mk3(ta.x, ta.y, ta.z), tb.x); // sphere.h:45
         r.normal = face_normal(d, outward, r.front_face);
         r.prim = f2i(ta.w);
     } else {
-        const Sphere sp = sc.spheres[(uint32_t)code - sc.ntris];
+        const Sphere sp = load_global(sc.spheres, (uint32_t)code - sc.ntris);
         const f3 outward = div3(r.point - mk3(sp.cx, sp.cy, sp.cz), sp.radius);
         r.normal = face_normal(d, outward, r.front_face);
         r.prim = sp.id;
