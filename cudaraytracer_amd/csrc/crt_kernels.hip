@@ -190,6 +190,10 @@ static_assert(CRT_WORK_STRIPES == 64u, "the order in which a wave visits the blo
 #ifndef CRT_NODE_CACHE_NODES
 #define CRT_NODE_CACHE_NODES 192 // 4 waves x 4.6 KB of stack + 12 KB of nodes = 30 KB per workgroup: five per CU = the same 20 waves
 #endif
+#ifndef CRT_LDS_VOTE_NUM
+#define CRT_LDS_VOTE_NUM 3 // an LDS-only node step when at least NUM/DEN of the lanes at a node are at a cached node
+#define CRT_LDS_VOTE_DEN 4
+#endif
 #ifndef CRT_LDS_STEPS_PER_VOTE
 #define CRT_LDS_STEPS_PER_VOTE 3 // node steps per vote when the nodes come from the LDS copy
 #endif
@@ -441,17 +445,17 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                 const int nw = n_inner + n_leaf;
                 if (nw == 0 || alive - nw >= threshold) break;
                 CRT_LAP(clk, 0);
-                // With the LDS copy of the top of the tree a node step is either all-LDS or all-global: a vector memory
-                // instruction occupies the CU's one address unit for 16 cycles whatever the number of active lanes, so a
-                // step that mixes both sources pays for both.
+                // With the LDS copy of the top of the tree there are two kinds of node step.  A vector memory instruction
+                // occupies the CU's one address unit for 16 cycles whatever the number of active lanes, so a step that
+                // fetches from device memory at all may as well do so for every lane at a node; when at least 3/4 of those
+                // lanes are at cached nodes the step is LDS-only instead and the others wait.
                 bool in_lds = false;
                 int n_lds = 0;
                 if constexpr (NC > 0) {
                     in_lds = inner && tv.cur < node_src.ncached;
                     n_lds = popc64(__ballot(in_lds));
                 }
-                const int n_glob = n_inner - n_lds;
-                if (NC > 0 && n_lds >= n_glob && n_lds >= n_leaf) {
+                if (NC > 0 && n_lds * CRT_LDS_VOTE_DEN >= n_inner * CRT_LDS_VOTE_NUM && n_lds >= n_leaf) {
                     if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_lds; } }
                     LdsNodes top;
                     top.lds = node_src.lds;
@@ -463,14 +467,15 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                         if (again) trav_inner_from(top, tv, stack, cnt);
                     }
                     CRT_LAP(clk, 7);
-                } else if (n_glob >= n_leaf) {
-                    const bool mine = inner && !in_lds;
-                    if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_glob; } }
+                } else if (n_inner >= n_leaf) {
+                    // (all lanes at a node take part: the loads cost the address unit the same whatever the number of lanes)
+                    const bool mine = inner;
+                    if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_inner; } }
                     if (mine) trav_inner(sc, tv, stack, cnt);
                     // more node steps on the same vote: descents come in runs, and the vote costs half a step in scalar work
 #pragma unroll
                     for (int k = 1; k < CRT_NODE_STEPS_PER_VOTE; k++) {
-                        const bool again = mine && is_inner(tv.cur) && (NC == 0 || tv.cur >= node_src.ncached);
+                        const bool again = mine && is_inner(tv.cur);
                         if constexpr (COUNT_WORK) { const int na = popc64(__ballot(again)); if (lane == 0) { wc[4]++; wc[5] += na; } }
                         if (again) trav_inner(sc, tv, stack, cnt);
                     }
