@@ -951,6 +951,7 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     const bool ss = sc.sphere_slots != 0;
     const int levels = ra.bvh_depth <= 16 ? 16 : ra.bvh_depth <= 24 ? 24 : CRT_STACK_DEPTH;
 #define CRT_LAUNCH(CW, SD, SS) do { if (a.node_cache && SD == 16) hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, CRT_NODE_CACHE_NODES>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters); \
+                                     else if (a.node_cache && SD == 24) hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, 64>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters); \
                                      else hipLaunchKernelGGL((render_kernel<CW, SD, SS, 1, 0>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters); } while (0)
 #define CRT_LAUNCH_SS(CW, SD) do { if (ss) CRT_LAUNCH(CW, SD, true); else CRT_LAUNCH(CW, SD, false); } while (0)
 #define CRT_LAUNCH_SD(CW) do { if (levels == 16) CRT_LAUNCH_SS(CW, 16); else if (levels == 24) CRT_LAUNCH_SS(CW, 24); else CRT_LAUNCH_SS(CW, CRT_STACK_DEPTH); } while (0)
