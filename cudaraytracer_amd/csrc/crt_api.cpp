@@ -664,7 +664,7 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
     ra.key0 = (uint32_t)p->seed; ra.key1 = (uint32_t)(p->seed >> 32);
     ra.kernel = get_env_int("CRT_KERNEL", 0) == 1 ? (uint32_t)RK_POOL : (uint32_t)RK_LANES;
     ra.sched_threshold = ra.kernel == RK_POOL ? (uint32_t)std::min(std::max(get_env_int("CRT_POOL_REFILL", 16), 1), 63)
-                                              : (uint32_t)std::min(std::max(get_env_int("CRT_SCHED_THRESHOLD", 40), 1), 64);
+                                              : (uint32_t)std::min(std::max(get_env_int("CRT_SCHED_THRESHOLD", 44), 1), 64);
     ra.bvh_depth = s->bvh.depth;
     ra.node_cache = get_env_int("CRT_NODE_CACHE", 1) ? 1u : 0u; // trees up to 16 deep: LDS copy of the top of the tree (launch_render)
     ra.blocks_per_stripe = get_env_int("CRT_STRIPE_BANDS", 1) ? 1u : 0u; // bands by default (+0.5 % cats, +2 % on the 1 M-triangle grid); launch_render sets the count
