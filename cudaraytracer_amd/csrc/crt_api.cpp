@@ -433,6 +433,7 @@ static bool commit_gpu_lbvh(crt_scene *s, int device, uint32_t max_leaf)
         s->rank[n + k] = r;
     }
     s->bvh = FlatBvh();
+    renumber_breadth_first(out.nodes, out.root_ref); // Karras numbering -> breadth first (the top of the tree goes to LDS)
     s->bvh.nodes.swap(out.nodes);
     s->bvh.tris.swap(out.slots);
     s->bvh.root_ref = out.root_ref; s->bvh.root_box = out.root_box; s->bvh.depth = out.depth; s->bvh.max_leaf = max_leaf;

@@ -261,6 +261,39 @@ struct Builder {
 
 } // namespace
 
+// Breadth-first node numbering: node index < N  <=>  one of the N nodes nearest the root, so "the top of the tree" is a
+// prefix of the array (the kernels keep that prefix in LDS).  Records that no reference reaches (the GPU builder leaves
+// the nodes of collapsed sub-trees behind) are dropped.  Triangle slots keep their order.
+void renumber_breadth_first(std::vector<q4> &nodes_io, int &root_ref)
+{
+    if (root_ref < 0 || root_ref == CRT_BVH_NONE) return;
+    const size_t n = nodes_io.size() / 4;
+    std::vector<int> order;        // new index -> old index
+    std::vector<int> renum(n, -1); // old index -> new index
+    order.reserve(n);
+    order.push_back(root_ref);
+    renum[(size_t)root_ref] = 0;
+    for (size_t head = 0; head < order.size(); head++) {
+        const q4 *q = &nodes_io[4 * (size_t)order[head]];
+        int r[2];
+        std::memcpy(&r[0], &q[0].w, 4); std::memcpy(&r[1], &q[1].w, 4);
+        for (int k = 0; k < 2; k++)
+            if (r[k] >= 0) { renum[(size_t)r[k]] = (int)order.size(); order.push_back(r[k]); }
+    }
+    std::vector<q4> nodes(4 * order.size());
+    for (size_t k = 0; k < order.size(); k++) {
+        const q4 *src = &nodes_io[4 * (size_t)order[k]];
+        q4 *dst = &nodes[4 * k];
+        for (int j = 0; j < 4; j++) dst[j] = src[j];
+        int r[2];
+        std::memcpy(&r[0], &src[0].w, 4); std::memcpy(&r[1], &src[1].w, 4);
+        for (int j = 0; j < 2; j++) if (r[j] >= 0) r[j] = renum[(size_t)r[j]];
+        std::memcpy(&dst[0].w, &r[0], 4); std::memcpy(&dst[1].w, &r[1], 4);
+    }
+    nodes_io.swap(nodes);
+    root_ref = 0;
+}
+
 void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t> &rank, const std::vector<BvhSphere> &spheres, uint32_t max_leaf,
                FlatBvh &out)
 {
@@ -303,35 +336,7 @@ void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t
     out.tris.reserve(3 * b.refs.size());
     out.root_ref = b.build(0, b.refs.size(), CRT_STACK_DEPTH, 1, out.root_box);
 
-    // Breadth-first node numbering: node index < N  <=>  one of the N nodes nearest the root, so "the top of the tree"
-    // is a prefix of the array (the kernels keep that prefix in LDS).  Triangle slots keep their depth-first order.
-    if (out.root_ref >= 0 && out.root_ref != CRT_BVH_NONE) {
-        const size_t n = out.nodes.size() / 4;
-        std::vector<int> order;      // new index -> old index
-        std::vector<int> renum(n, -1); // old index -> new index
-        order.reserve(n);
-        order.push_back(out.root_ref);
-        renum[(size_t)out.root_ref] = 0;
-        for (size_t head = 0; head < order.size(); head++) {
-            const q4 *q = &out.nodes[4 * (size_t)order[head]];
-            int r[2];
-            std::memcpy(&r[0], &q[0].w, 4); std::memcpy(&r[1], &q[1].w, 4);
-            for (int k = 0; k < 2; k++)
-                if (r[k] >= 0) { renum[(size_t)r[k]] = (int)order.size(); order.push_back(r[k]); }
-        }
-        std::vector<q4> nodes(out.nodes.size());
-        for (size_t k = 0; k < order.size(); k++) {
-            const q4 *src = &out.nodes[4 * (size_t)order[k]];
-            q4 *dst = &nodes[4 * k];
-            for (int j = 0; j < 4; j++) dst[j] = src[j];
-            int r[2];
-            std::memcpy(&r[0], &src[0].w, 4); std::memcpy(&r[1], &src[1].w, 4);
-            for (int j = 0; j < 2; j++) if (r[j] >= 0) r[j] = renum[(size_t)r[j]];
-            std::memcpy(&dst[0].w, &r[0], 4); std::memcpy(&dst[1].w, &r[1], 4);
-        }
-        out.nodes.swap(nodes);
-        out.root_ref = 0;
-    }
+    renumber_breadth_first(out.nodes, out.root_ref);
 }
 
 } // namespace crt

@@ -43,4 +43,7 @@ struct BvhSphere { HostSphere s; uint32_t id; uint32_t rank; };
 void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t> &rank, const std::vector<BvhSphere> &spheres, uint32_t max_leaf,
                FlatBvh &out);
 
+// Breadth-first renumbering of a flattened tree (drops unreachable records): what "the first N nodes" means to the kernels.
+void renumber_breadth_first(std::vector<q4> &nodes, int &root_ref);
+
 } // namespace crt
