@@ -17,7 +17,7 @@ struct RenderArgs {
     uint32_t spp, sample_offset, max_depth, ids_sample;
     uint32_t tile_rank, tile_ranks, flags;
     uint32_t key0, key1;
-    uint32_t local_pixels;    // 64 * (tiles of this rank): pixel slots handed out by the device-wide counter (set by launch_render)
+    uint32_t local_pixels;    // 64 * (tiles of this rank): pixel slots of the work queue (set by launch_render)
     uint32_t sched_threshold; // RK_LANES: lanes that must wait for the shade/regenerate phase before it runs (1..64)
                               // RK_POOL: free lanes that end a run of walk steps (1..63)
     uint32_t chunks;          // sample chunks per pixel (a power of two dividing spp): work unit = (pixel, chunk)

@@ -155,28 +155,30 @@ struct SectionClock {
 // Lane phases while not walking (a lane walks the BVH iff tv.cur != CRT_BVH_NONE)
 enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
 
-// render_kernel: one wave64 per workgroup, persistent.  A lane computes a pixel start to finish (its samples summed in
-// sample order, renderer.h:28-32, so the float sum is the reference's whatever the partition) and takes pixels from a
-// device-wide counter in 8x8-tile order (q = 64 * tile + lane-in-tile), so a lane that finishes its pixel does not wait
-// for the slowest lane of its tile.
+// render_kernel: persistent waves, each on its own (W = 1: one per workgroup; W = 4: four per workgroup that share an LDS
+// copy of the top of the tree and otherwise never meet).  A lane owns one work unit at a time: a pixel, its samples summed
+// in sample order (renderer.h:28-32, so the float sum is the reference's whatever the partition), or with sample chunks one
+// chunk of a pixel's samples; units are numbered in 8x8-tile order and handed out in blocks of 64 from striped counters
+// (phase A below), so a lane that finishes does not wait for the slowest lane of its tile.
 //
 // Divergence control.  Paths end after 1..max_depth segments; 58 % of the segments of the headline scene never enter
 // the triangle BVH (they miss its root box), the others walk 14 steps on average with a long tail.  Lock-step "sample
 // loop / bounce loop / traversal loop" nesting leaves ~80 % of the lanes idle (profiles/r1_v1_nested_loops).  Here
 // every lane is a small state machine
-//     FETCH (needs a pixel) -> NEW (needs a camera ray) -> walking -> HIT (walk over: resolve, shade, scatter) -> ...
+//     FETCH (needs a unit) -> NEW (needs a camera ray) -> walking -> HIT (walk over: resolve, shade, scatter) -> ...
 // and the wave alternates, by 64-bit ballots, between two phases:
 //   A  "shade", run when at least `sched_threshold` lanes are not walking (or nobody walks): HIT lanes resolve their
-//      hit, fetch primitive and shading record together, add emission and end the path or scatter (own Philox block);
-//      finished pixels are stored and new ones fetched; NEW lanes build the next sample's camera ray (own Philox block,
-//      defocus-disk rejection loop inline, utility.h:100-109); then the sphere tests and the root-box test start the
-//      next walk.
-//   B  "walk": node steps for the lanes at a node or one leaf step for the lanes at a leaf, whichever group is larger,
-//      until enough lanes wait for phase A again.  A vote is followed by up to CRT_NODE_STEPS_PER_VOTE node steps.
+//      hit, fetch primitive and shading record together, add emission and end the path or scatter; finished units are
+//      stored and new ones fetched; NEW lanes build the next sample's camera ray (one Philox evaluation serves both kinds
+//      of lane; defocus-disk rejection loop inline, utility.h:100-109); then the sphere tests and the root-box test
+//      start the next walk.
+//   B  "walk": by vote, node steps for the lanes at a node (LDS-only steps or device-memory steps, see the loop) or one
+//      leaf step for the lanes at a leaf, until enough lanes wait for phase A again.
 // A lane's own operation sequence is exactly the sequential one (crt_traverse.h: sample_radiance), so results do not
-// depend on the schedule.  The kernel is bound by VALU issue (98 % of SIMD time), so the code below
-// is written to keep scalar bookkeeping and register shuffling out of the loops; what was tried and rejected is listed
-// in DESIGN.md section 7.
+// depend on the schedule.  The kernel is bound by VALU issue in phase A and by the CU's one address unit (16 cycles per
+// vector memory instruction whatever the number of lanes) in phase B, so the code below keeps
+// scalar bookkeeping and register shuffling out of the loops, reads uniform data through scalar loads and the top of
+// the tree from LDS; what was tried and rejected is listed in DESIGN.md section 7.
 #ifndef CRT_FETCH_BLOCK
 #define CRT_FETCH_BLOCK 64u // work units per block (>= 64: one block always covers a wave's request)
 #endif
