@@ -197,7 +197,7 @@ static_assert(CRT_WORK_STRIPES == 64u, "the order in which a wave visits the blo
 #define CRT_LDS_VOTE_DEN 4
 #endif
 #ifndef CRT_LDS_STEPS_PER_VOTE
-#define CRT_LDS_STEPS_PER_VOTE 3 // node steps per vote when the nodes come from the LDS copy
+#define CRT_LDS_STEPS_PER_VOTE 4 // node steps per vote when the nodes come from the LDS copy
 #endif
 #ifndef CRT_WAVES_PER_EU
 #define CRT_WAVES_PER_EU 5 // 512 VGPRs / 5 waves -> 96 registers per lane; the few spills this forces sit on the rare tie path
