@@ -667,7 +667,7 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
     ra.sched_threshold = ra.kernel == RK_POOL ? (uint32_t)std::min(std::max(get_env_int("CRT_POOL_REFILL", 16), 1), 63)
                                               : (uint32_t)std::min(std::max(get_env_int("CRT_SCHED_THRESHOLD", 44), 1), 64);
     ra.bvh_depth = s->bvh.depth;
-    ra.node_cache = get_env_int("CRT_NODE_CACHE", 1) ? 1u : 0u; // trees up to 16 deep: LDS copy of the top of the tree (launch_render)
+    ra.node_cache = (uint32_t)std::min(std::max(get_env_int("CRT_NODE_CACHE", 1), 0), 2); // 0 off, 1 when the frame fills the GPU, 2 always; // trees up to 16 deep: LDS copy of the top of the tree (launch_render)
     ra.blocks_per_stripe = get_env_int("CRT_STRIPE_BANDS", 1) ? 1u : 0u; // bands by default (+0.5 % cats, +2 % on the 1 M-triangle grid); launch_render sets the count
 
     const size_t npix = (size_t)p->width * p->height;

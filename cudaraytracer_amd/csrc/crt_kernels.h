@@ -24,7 +24,7 @@ struct RenderArgs {
     uint32_t chunk_shift;     // log2(chunks)                                  (set by launch_render)
     uint32_t tiles_x_magic;   // floor(2^32 / tiles_x) for the kernel's tile -> (column, row) division (set by launch_render)
     uint32_t blocks_per_stripe; // in: non-zero = each block counter owns a contiguous band of the frame; launch_render sets the count
-    uint32_t node_cache;      // non-zero: 5 waves per workgroup sharing an LDS copy of the first 256 nodes (trees up to 16 deep)
+    uint32_t node_cache;      // four waves per workgroup sharing an LDS copy of the top of the tree (trees up to 24 deep): 0 never, 1 when the frame fills the GPU, 2 always
     uint32_t chunk_stride;    // pixels per chunk slab of the scratch the kernel writes when chunks > 1
     uint32_t kernel;          // RK_*
     uint32_t bvh_depth;       // levels of the triangle BVH (selects the LDS stack size)

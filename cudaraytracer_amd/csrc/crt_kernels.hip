@@ -951,6 +951,7 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     // the LDS stack is sized by the tree: 16 levels (4.6 KB per wave), 24 (6.7 KB: still the 20 waves per CU the registers
     // allow) or 32 (8.7 KB: 18 waves per CU)
     const bool ss = sc.sphere_slots != 0;
+    if (a.node_cache == 1 && units < max_waves) a.node_cache = 0; // a frame that does not fill the GPU: single waves spread over more CUs than groups of four (2 = always)
     const int levels = ra.bvh_depth <= 16 ? 16 : ra.bvh_depth <= 24 ? 24 : CRT_STACK_DEPTH;
 #define CRT_LAUNCH(CW, SD, SS) do { if (a.node_cache && SD == 16) hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, CRT_NODE_CACHE_NODES>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters); \
                                      else if (a.node_cache && SD == 24) hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, 64>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters); \

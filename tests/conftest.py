@@ -53,3 +53,12 @@ def capi():
 def scenes(capi):
     from cudaraytracer_amd import scenes as s
     return s
+
+
+@pytest.fixture(params=["0", "2"], ids=["one-wave-groups", "lds-node-copy"])
+def node_cache(request, monkeypatch):
+    """Runs a GPU test with both kernel variants: one wave per workgroup (CRT_NODE_CACHE=0) and four waves sharing an LDS copy
+    of the top of the tree (CRT_NODE_CACHE=2: always; the default, 1, picks it only for frames that fill the GPU, which
+    test-sized frames do not)."""
+    monkeypatch.setenv("CRT_NODE_CACHE", request.param)
+    return request.param

@@ -183,7 +183,7 @@ def test_full_size_properties_1080p_64spp(scenes, gpu_scenes, capi):
     assert np.isfinite(img).all() and img.min() >= 0 and img[600:, :].mean() > 0.01
 
 
-def test_grid_scene_1m_triangles_sample(oracle, scenes, capi):
+def test_grid_scene_1m_triangles_sample(oracle, scenes, capi, node_cache):
     """BASELINE config 4 geometry (999,912 triangles): BVH depth within the stack, and a window of primary rays + a
     low-resolution full path render bit-exact against the oracle (reference traversal, no culling -> small sizes)."""
     desc = scenes.cat_grid()
@@ -214,7 +214,7 @@ def test_context_pool_kernel_matches_default_kernel(monkeypatch, scenes, gpu_sce
         assert np.array_equal(rgb0, rgb1) and np.array_equal(ids0, ids1) and st0.rays == st1.rays
 
 
-def test_sample_chunks_match_chunked_sum_of_oracle(oracle, scenes, gpu_scenes):
+def test_sample_chunks_match_chunked_sum_of_oracle(oracle, scenes, gpu_scenes, node_cache):
     """sample_chunks = n: the work unit is (pixel, chunk of spp/n samples); every sample is the same, each chunk is
     summed in sample order and the chunk sums are added in chunk order.  The oracle's raw sums per chunk, combined the
     same way in float32, must reproduce the image bit for bit; against the unchunked image the tolerance is float
@@ -244,7 +244,7 @@ def test_sample_chunks_match_chunked_sum_of_oracle(oracle, scenes, gpu_scenes):
     assert np.array_equal(full.reshape(expect.shape), expect)
 
 
-def test_sphere_scene_on_gpu(oracle, scenes, gpu_scenes, monkeypatch):
+def test_sphere_scene_on_gpu(oracle, scenes, gpu_scenes, monkeypatch, node_cache):
     """Row N3 (scene.h:53-90): 488 spheres (487 of them sphere slots of the BVH), Lambertian / Metal / Dielectric, both
     kernels, whole pixels and sample chunks."""
     rgb, ids, st, _ = _compare(oracle, scenes, gpu_scenes, "random_spheres", 320, 180, 4, camera=scenes.SPHERES_CAMERA)
@@ -278,7 +278,7 @@ def test_gpu_lbvh_builder_same_ranks_same_image(oracle, capi, scenes, name):
     assert np.array_equal(ids_g, rids) and np.array_equal(rgb_g.reshape(fb.shape), fb) and st_g.rays == rst.rays
 
 
-def test_gpu_lbvh_builder_on_the_1m_triangle_scene(capi, scenes):
+def test_gpu_lbvh_builder_on_the_1m_triangle_scene(capi, scenes, node_cache):
     desc = scenes.cat_grid()
     host = scenes.build(desc, 0)
     gpu = scenes.build(desc, 0, capi.BUILD_GPU_LBVH)
@@ -293,7 +293,7 @@ def test_gpu_lbvh_builder_on_the_1m_triangle_scene(capi, scenes):
     assert np.array_equal(ids_g, ids_h) and np.array_equal(rgb_g, rgb_h) and st_g.rays == st_h.rays
 
 
-def test_randomised_configurations_against_oracle(oracle, scenes, gpu_scenes, capi):
+def test_randomised_configurations_against_oracle(oracle, scenes, gpu_scenes, capi, node_cache):
     """A sweep over odd frame sizes, seeds, depths, sample windows, partitions and chunk counts: every one bit-exact against
     the oracle (chunked runs against the oracle's chunk sums combined in chunk order)."""
     rng = np.random.default_rng(20240611)
