@@ -393,3 +393,34 @@ def test_many_sample_chunks(oracle, scenes, gpu_scenes, capi, spp, n):
     acc, ids, st = s.render(cam, width, height, spp, want_ids=True, ids_sample=spp - 1, flags=capi.OUT_ACCUM, sample_chunks=n)
     assert st.rays == rays and np.array_equal(ids, rids)
     assert np.array_equal(acc.reshape(total.shape), total)
+
+
+def _degenerate_scene(scenes, capi, kind):
+    d = scenes._base()
+    scenes._add_ref_spheres(d)                        # ground + light (flat list)
+    d["materials"].append(dict(type=capi.MAT_LAMBERTIAN, rgb=(0.7, 0.3, 0.16), param=0.0, texture=None))
+    mat = len(d["materials"]) - 1
+    if kind == "spheres_only":                        # no triangles at all: no tree, root reference = none
+        d["materials"].append(dict(type=capi.MAT_METAL, rgb=(0.8, 0.8, 0.8), param=0.1, texture=None))
+        d["spheres"].append(dict(center=(0.0, 1.0, 0.0), radius=1.0, material=mat))
+        d["spheres"].append(dict(center=(2.2, 0.7, 0.5), radius=0.7, material=len(d["materials"]) - 1))
+    else:                                             # 1 triangle: the root is a leaf; 3: one node above two leaves
+        n = 1 if kind == "one_triangle" else 3
+        v = np.array([[-2.0, 0.0, -1.0], [2.0, 0.0, -1.0], [0.0, 3.0, 0.0], [-2.5, 0.2, 1.0], [-0.5, 0.2, 1.5], [-1.5, 2.0, 1.2],
+                      [0.5, 0.1, 2.0], [2.5, 0.1, 1.5], [1.5, 1.8, 1.8]], dtype=np.float32)[: 3 * n]
+        idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+        d["meshes"].append(dict(vertices=v, indices=idx, material=mat))
+    return d
+
+
+@pytest.mark.parametrize("kind", ["spheres_only", "one_triangle", "three_triangles"])
+def test_degenerate_trees(oracle, scenes, capi, node_cache, kind):
+    """Scenes whose tree is missing (spheres only), a single leaf, or a single node: ids, image and ray count against the oracle."""
+    desc = _degenerate_scene(scenes, capi, kind)
+    s = scenes.build(desc, 0)
+    width, height, spp = 96, 54, 3
+    params, cam = scenes.make_camera(width)
+    rgb, ids, st = s.render(cam, width, height, spp, want_ids=True, ids_sample=1)
+    fb, rids, _, rst = oracle.RefScene(desc).render(oracle.make_camera(params, width), width, height, spp, ids_sample=1)
+    assert np.array_equal(ids, rids) and np.array_equal(rgb, fb) and st.rays == rst.rays
+    assert (ids >= 0).any()
