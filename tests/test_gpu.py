@@ -424,3 +424,15 @@ def test_degenerate_trees(oracle, scenes, capi, node_cache, kind):
     fb, rids, _, rst = oracle.RefScene(desc).render(oracle.make_camera(params, width), width, height, spp, ids_sample=1)
     assert np.array_equal(ids, rids) and np.array_equal(rgb, fb) and st.rays == rst.rays
     assert (ids >= 0).any()
+
+
+@pytest.mark.parametrize("kind", ["spheres_only", "one_triangle", "three_triangles"])
+def test_degenerate_trees_from_the_gpu_builder(oracle, scenes, capi, kind):
+    """The same degenerate scenes committed through the GPU builder (a scene without triangles has nothing to build there)."""
+    desc = _degenerate_scene(scenes, capi, kind)
+    s = scenes.build(desc, 0, flags=capi.BUILD_GPU_LBVH)
+    width, height, spp = 96, 54, 2
+    params, cam = scenes.make_camera(width)
+    rgb, ids, st = s.render(cam, width, height, spp, want_ids=True)
+    fb, rids, _, rst = oracle.RefScene(desc).render(oracle.make_camera(params, width), width, height, spp)
+    assert np.array_equal(ids, rids) and np.array_equal(rgb, fb) and st.rays == rst.rays
