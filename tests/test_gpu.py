@@ -444,3 +444,27 @@ def test_other_cameras(oracle, scenes, gpu_scenes, node_cache, camera):
     """Pinhole camera (no defocus disk: camera.h:89 takes the centre), a wide lens (most disk draws are retried at least once
     somewhere in a wave), a top view with another up vector and a square aspect."""
     _compare(oracle, scenes, gpu_scenes, "cats", 120, 67 if "aspect" not in camera else 120, 3, camera=camera, ids_sample=2)
+
+
+def test_dielectric_and_checker_meshes(oracle, scenes, capi, node_cache):
+    """A glass cat beside a metal one on a checkered ground sphere: refraction / total reflection through triangle meshes
+    (material.h:61-91 with triangle normals) and the checker's sign handling on a large sphere (texture.h:31-39)."""
+    d = scenes._base()
+    v, i = capi.load_obj(os.path.join(scenes.MODELS, "cat.obj"))
+    v = v[:, :3].copy()
+    d["materials"].append(dict(type=capi.MAT_DIELECTRIC, rgb=(1.0, 1.0, 1.0), param=1.5, texture=None))
+    d["materials"].append(dict(type=capi.MAT_METAL, rgb=(0.9, 0.6, 0.2), param=0.3, texture=None))
+    d["meshes"].append(dict(vertices=v, indices=i, material=0))
+    d["meshes"].append(dict(vertices=v + np.array([2.5, 0.0, 1.0], np.float32), indices=i, material=1))
+    d["textures"].append(dict(type=capi.TEX_CHECKER, a=(0.2, 0.3, 0.1), b=(0.9, 0.9, 0.9), scale=0.7))
+    d["materials"].append(dict(type=capi.MAT_LAMBERTIAN, rgb=(0.5, 0.5, 0.5), param=0.0, texture=0))
+    d["materials"].append(dict(type=capi.MAT_DIFFUSE_LIGHT, rgb=(15.0, 15.0, 15.0), param=0.0, texture=None))
+    d["spheres"].append(dict(center=(0.0, -1000.0, -1.0), radius=1000.0, material=2))
+    d["spheres"].append(dict(center=(3.0, 6.5, 3.0), radius=2.0, material=3))
+    s = scenes.build(d, 0)
+    width, height, spp = 160, 90, 4
+    params, cam = scenes.make_camera(width)
+    rgb, ids, st = s.render(cam, width, height, spp, want_ids=True, max_depth=12)
+    fb, rids, _, rst = oracle.RefScene(d).render(oracle.make_camera(params, width), width, height, spp, max_depth=12)
+    assert np.array_equal(ids, rids) and st.rays == rst.rays
+    assert np.array_equal(rgb, fb), "PSNR %.1f dB" % helpers.psnr(rgb, fb)
