@@ -237,9 +237,10 @@ struct crt_scene {
     std::vector<uint32_t> rank;
     FlatBvh bvh;
     std::vector<Shade> shades; // materials joined with their textures (device record)
+    std::vector<q4> normals;   // per triangle slot: unit normal + primitive id (crt_traverse.h: triangle_normal)
     uint32_t builder = 0; float build_ms = 0.0f;
     std::vector<Sphere> flat_spheres; // the spheres that are tested before the walk (the others are slots of the tree)
-    void *d_nodes = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_shades = nullptr;
+    void *d_nodes = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_shades = nullptr, *d_normals = nullptr;
     uint32_t max_waves = 0; // persistent-grid size: compute units x wave slots
     SceneView view{};
     // Per-stream scratch: work counters, sample-chunk slabs (grow only: chunks x frame floats, summed in chunk order by
@@ -277,9 +278,9 @@ struct crt_scene {
     void release_device()
     {
         if (device >= 0) (void)hipSetDevice(device);
-        void *ptrs[] = { d_nodes, d_tris, d_spheres, d_shades, d_stage_rgb, d_stage_ids };
+        void *ptrs[] = { d_nodes, d_tris, d_spheres, d_shades, d_normals, d_stage_rgb, d_stage_ids };
         for (void *p : ptrs) if (p) (void)hipFree(p);
-        d_nodes = d_tris = d_spheres = d_shades = nullptr; d_stage_rgb = nullptr; d_stage_ids = nullptr;
+        d_nodes = d_tris = d_spheres = d_shades = d_normals = nullptr; d_stage_rgb = nullptr; d_stage_ids = nullptr;
         stage_rgb_floats = stage_ids = 0;
         for (StreamScratch &x : scratch) {
             if (x.d_counters) (void)hipFree(x.d_counters);
@@ -518,6 +519,19 @@ extern "C" int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags)
         }
     }
 
+    // the unit normal of every triangle slot, with the operations the hit record uses (sphere slots: unused)
+    {
+        const size_t nslots = s->bvh.tris.size() / 3;
+        s->normals.resize(nslots);
+        for (size_t k = 0; k < nslots; k++) {
+            const q4 *tp = &s->bvh.tris[3 * k];
+            int rank_word;
+            std::memcpy(&rank_word, &tp[1].w, 4);
+            if (rank_word & CRT_SPHERE_SLOT) { q4 z; z.x = z.y = z.z = 0.0f; z.w = tp[0].w; s->normals[k] = z; }
+            else s->normals[k] = triangle_normal(tp[0], tp[1], tp[2]);
+        }
+    }
+
     s->prepared = true;
     if (device == CRT_DEVICE_NONE) return CRT_OK; // host-side preparation only (ranks, BVH); rendering stays unavailable
 
@@ -531,6 +545,7 @@ extern "C" int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags)
     if ((rc = upload(&s->d_tris, s->bvh.tris))) return rc;
     if ((rc = upload(&s->d_spheres, spheres))) return rc;
     if ((rc = upload(&s->d_shades, s->shades))) return rc;
+    if ((rc = upload(&s->d_normals, s->normals))) return rc;
     {
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device));
@@ -539,7 +554,7 @@ extern "C" int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags)
     }
     SceneView &v = s->view;
     v.nodes = (const q4 *)s->d_nodes; v.tris = (const q4 *)s->d_tris; v.spheres = (const Sphere *)s->d_spheres;
-    v.shades = (const Shade *)s->d_shades;
+    v.shades = (const Shade *)s->d_shades; v.normals = (const q4 *)s->d_normals;
     v.root_ref = s->bvh.root_ref; v.nnodes = (uint32_t)(s->bvh.nodes.size() / 4); v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size(); v.sphere_slots = tree_spheres.empty() ? 0u : 1u;
     v.root_min = s->bvh.root_box.mn; v.root_max = s->bvh.root_box.mx;
     s->committed = true;

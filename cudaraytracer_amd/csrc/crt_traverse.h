@@ -45,6 +45,7 @@ struct SceneView {
     const q4 *tris;
     const Sphere *spheres;
     const Shade *shades; // per material id
+    const q4 *normals;   // per triangle slot: unit normal of the triangle as triangle.h:81 computes it, primitive id in w
     int root_ref;        // BVH_NONE when there are no triangles
     uint32_t nnodes;     // 64-byte nodes (breadth-first order: crt_bvh.cpp)
     uint32_t ntris;      // triangle slots
@@ -328,18 +329,28 @@ CRT_HD int closest_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, 
 // (triangle.h:78-83, sphere.h:43-47, hittable.h:18-21).
 struct Surface { f3 point, normal; bool front_face; int prim; };
 
+// triangle.h:81 for the triangle of one 48-byte slot; w carries the primitive id
+CRT_HD q4 triangle_normal(q4 ta, q4 tb, q4 tc)
+{
+    const f3 a = mk3(ta.x, ta.y, ta.z);
+    const f3 n = normalize(cross(mk3(tb.x, tb.y, tb.z) - a, mk3(tc.x, tc.y, tc.z) - a));
+    q4 r;
+    r.x = n.x; r.y = n.y; r.z = n.z; r.w = ta.w;
+    return r;
+}
+
 template <bool SPHERE_SLOTS = true>
 CRT_HD Surface surface_at(const SceneView &sc, int code, f3 o, f3 d, float t)
 {
     Surface r;
     r.point = axpy(t, d, o);
     if ((uint32_t)code < sc.ntris) {
-        const size_t k = 3 * (size_t)code;
-        const q4 ta = load_global(sc.tris, k), tb = load_global(sc.tris, k + 1), tc = load_global(sc.tris, k + 2);
-        const f3 a = mk3(ta.x, ta.y, ta.z);
-        const f3 n = normalize(cross(mk3(tb.x, tb.y, tb.z) - a, mk3(tc.x, tc.y, tc.z) - a));
-        r.normal = face_normal(d, n, r.front_face);
-        r.prim = f2i(ta.w);
+        // normalize(cross(b - a, c - a)) (triangle.h:81) does not depend on the ray: evaluated once per triangle at commit by
+        // triangle_normal() below -- the same operations, so the same bits -- and fetched as one 16-byte record instead of the
+        // triangle's three
+        const q4 nn = load_global(sc.normals, (size_t)code);
+        r.normal = face_normal(d, mk3(nn.x, nn.y, nn.z), r.front_face);
+        r.prim = f2i(nn.w);
     } else if (SPHERE_SLOTS && (code & CRT_SPHERE_SLOT)) {
         const size_t k = 3 * (size_t)(code & ~CRT_SPHERE_SLOT);
         const q4 ta = load_global(sc.tris, k), tb = load_global(sc.tris, k + 1);
