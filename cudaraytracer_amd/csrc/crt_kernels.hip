@@ -237,10 +237,11 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
     stack.init(lds_stack + lane);
     typename std::conditional<COUNT_WORK, RegCounters<SS>, RayCounters<SS>>::type cnt;
 
-    uint32_t q = NO_PIXEL, i = 0, j = 0, pixel = 0;
+    uint32_t q = NO_PIXEL, ij = 0, pixel = 0; // ij = column | row << 16 of the pixel (both < 65536)
     f3 col = mk3(0.0f, 0.0f, 0.0f);
-    int primary = -1, path_prim = -1;
+    int primary = -1; // primitive id of the primary hit of sample `ids_sample`, if this unit renders that sample
     int phase = P_FETCH;
+    uint32_t rays_wave = 0;
     uint32_t blk_next = 0, blk_end = 0; // the wave's block of work units [blk_next, blk_end) (wave-uniform)
     uint32_t stripe = home, stripes_left = CRT_WORK_STRIPES; // counter in use, counters not yet seen empty
     uint32_t s_idx = 0, s_end = 0, depth = 0; // samples [s_idx, s_end) of the pixel are still to do (s_end = spp without chunks)
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                     const Shade m = load_global(sck.shades, (size_t)mat); // issued together with the primitive fetch below: one memory round trip per hit
                     sf = surface_at<SS>(sck, code, p.o, p.d, t);
                     cnt.shade();
-                    if (depth == 0) path_prim = sf.prim;
+                    if (depth == 0 && ra.sample_offset + s_idx == ra.ids_sample) primary = sf.prim;
                     m_type = m.type; m_param = m.param;
                     colour = texture_value(m, sf.point);
                     const f3 e = emitted(m_type, colour); // camera.h:73-74
@@ -303,7 +304,6 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                 }
                 if (!want_scatter) { // path over: renderer.h:31
                     col = col + p.color;
-                    if (ra.sample_offset + s_idx == ra.ids_sample) primary = path_prim;
                     s_idx++;
                     phase = s_idx < s_end ? P_NEW : P_FETCH;
                 }
@@ -380,8 +380,8 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                         // tile / tiles_x by the host's floor(2^32 / tiles_x): at most one too small
                         uint32_t ty = __umulhi(tile, rak.tiles_x_magic), tx = tile - ty * rak.tiles_x;
                         if (tx >= rak.tiles_x) { tx -= rak.tiles_x; ty++; }
-                        i = tx * 8u + (l & 7u);
-                        j = ty * 8u + (l >> 3);
+                        const uint32_t i = tx * 8u + (l & 7u), j = ty * 8u + (l >> 3);
+                        ij = i | (j << 16);
                         if (i < rak.width && j < rak.height) { // renderer.h:22
                             pixel = j * rak.width + i;      // renderer.h:24
                             s_idx = chunk * chunk_spp;
@@ -400,8 +400,8 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                 }
             }
             CRT_LAP(clk, 2);
+            bool has_ray = false;
             if (active) {
-                bool has_ray = false;
                 // one Philox evaluation for both kinds of lane: stage 1 + depth for a scatter, stage 0 block 0 for a camera ray
                 u4 r;
                 r.x = r.y = r.z = r.w = 0u;
@@ -422,21 +422,20 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                 CRT_LAP(clk, 4);
                 if (phase == P_NEW) {
                     const CameraPOD camk = load_kernel_arg<CameraPOD>(offsetof(KernelArgsLayout, cam));
-                    camera_ray_from(camk, i, j, pixel, ra.sample_offset + s_idx, key0, key1, r, p.o, p.d);
+                    camera_ray_from(camk, ij & 0xFFFFu, ij >> 16, pixel, ra.sample_offset + s_idx, key0, key1, r, p.o, p.d);
                     p.attenuation = mk3(1.0f, 1.0f, 1.0f);
                     p.color = mk3(0.0f, 0.0f, 0.0f);
                     depth = 0;
-                    path_prim = -1;
                     has_ray = true;
                 }
                 CRT_LAP(clk, 5);
                 if (has_ray) {
-                    cnt.ray();
                     hit.t = FLT_MAX; hit.code = -1; hit.near_tie = false;
                     trav_begin<MODE_CLOSEST>(sck, p.o, p.d, tmin, hit, 0, 0.0f, tv, stack, cnt);
                     phase = P_HIT; // what the lane does once tv.cur is CRT_BVH_NONE again (at once if the root box is missed)
                 }
             }
+            rays_wave += (uint32_t)popc64(__ballot(has_ray)); // path segments, counted per wave (uniform: a scalar register)
             CRT_LAP(clk, 6);
         } else {
             // ================================ phase B ================================
@@ -491,7 +490,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
         }
     }
 
-    const uint32_t rays = wave_sum(cnt.rays), refolds = wave_sum(cnt.refolds);
+    const uint32_t rays = rays_wave, refolds = wave_sum(cnt.refolds);
     if (lane == 0) {
         atomicAdd(&counters[0], (unsigned long long)rays);
         if (refolds) atomicAdd(&counters[4], (unsigned long long)refolds);
