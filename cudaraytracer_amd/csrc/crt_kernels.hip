@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
     uint32_t rays_wave = 0;
     uint32_t blk_next = 0, blk_end = 0; // the wave's block of work units [blk_next, blk_end) (wave-uniform)
     uint32_t stripe = home, stripes_left = CRT_WORK_STRIPES; // counter in use, counters not yet seen empty
-    uint32_t s_idx = 0, s_end = 0, depth = 0; // samples [s_idx, s_end) of the pixel are still to do (s_end = spp without chunks)
+    uint32_t samples = 0, depth = 0; // samples = index of the current sample | samples still to do << 16 (both <= 65535: crt_render's limits)
     Path p;
     p.o = p.d = p.attenuation = p.color = mk3(0.0f, 0.0f, 0.0f);
     Search hit;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                     const Shade m = load_global(sck.shades, (size_t)mat); // issued together with the primitive fetch below: one memory round trip per hit
                     sf = surface_at<SS>(sck, code, p.o, p.d, t);
                     cnt.shade();
-                    if (depth == 0 && ra.sample_offset + s_idx == ra.ids_sample) primary = sf.prim;
+                    if (depth == 0 && ra.sample_offset + (samples & 0xFFFFu) == ra.ids_sample) primary = sf.prim;
                     m_type = m.type; m_param = m.param;
                     colour = texture_value(m, sf.point);
                     const f3 e = emitted(m_type, colour); // camera.h:73-74
@@ -304,8 +304,8 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                 }
                 if (!want_scatter) { // path over: renderer.h:31
                     col = col + p.color;
-                    s_idx++;
-                    phase = s_idx < s_end ? P_NEW : P_FETCH;
+                    samples += 1u - 0x10000u; // next index, one fewer to do
+                    phase = samples >= 0x10000u ? P_NEW : P_FETCH;
                 }
             }
             CRT_LAP(clk, 1);
@@ -384,8 +384,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                         ij = i | (j << 16);
                         if (i < rak.width && j < rak.height) { // renderer.h:22
                             pixel = j * rak.width + i;      // renderer.h:24
-                            s_idx = chunk * chunk_spp;
-                            s_end = s_idx + chunk_spp;
+                            samples = (chunk * chunk_spp) | (chunk_spp << 16);
                             col = mk3(0.0f, 0.0f, 0.0f);
                             primary = -1;
                             phase = P_NEW;
@@ -409,7 +408,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                 // whole kernel that live in spilled scalar registers and come back as v_readlane)
                 uint32_t key0 = ra.key0, key1 = ra.key1;
                 asm volatile("" : "+s"(key0), "+s"(key1));
-                if (want_scatter || phase == P_NEW) r = philox4x32_10(pixel, ra.sample_offset + s_idx, want_scatter ? 1u + depth : 0u, 0u, key0, key1);
+                if (want_scatter || phase == P_NEW) r = philox4x32_10(pixel, ra.sample_offset + (samples & 0xFFFFu), want_scatter ? 1u + depth : 0u, 0u, key0, key1);
                 CRT_LAP(clk, 3);
                 if (want_scatter) {
                     f3 att, no, nd;
@@ -422,7 +421,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                 CRT_LAP(clk, 4);
                 if (phase == P_NEW) {
                     const CameraPOD camk = load_kernel_arg<CameraPOD>(offsetof(KernelArgsLayout, cam));
-                    camera_ray_from(camk, ij & 0xFFFFu, ij >> 16, pixel, ra.sample_offset + s_idx, key0, key1, r, p.o, p.d);
+                    camera_ray_from(camk, ij & 0xFFFFu, ij >> 16, pixel, ra.sample_offset + (samples & 0xFFFFu), key0, key1, r, p.o, p.d);
                     p.attenuation = mk3(1.0f, 1.0f, 1.0f);
                     p.color = mk3(0.0f, 0.0f, 0.0f);
                     depth = 0;
