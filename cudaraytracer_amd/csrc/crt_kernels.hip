@@ -30,6 +30,7 @@ template <bool SS>
 struct RegCounters {
     static constexpr bool sphere_slots = SS;
     uint32_t nodes = 0, tris = 0, spheres = 0, rays = 0, refolds = 0, shades = 0;
+    unsigned long long *refold_counter = nullptr; // (unused here: refolds are summed with the other counters)
     __device__ __forceinline__ void node() { nodes++; }
     __device__ __forceinline__ void tri() { tris++; }
     __device__ __forceinline__ void sphere() { spheres++; }
@@ -40,12 +41,13 @@ struct RegCounters {
 template <bool SS>
 struct RayCounters { // always-on: rays and tie refolds only
     static constexpr bool sphere_slots = SS;
-    uint32_t rays = 0, refolds = 0;
+    uint32_t rays = 0;
+    unsigned long long *refold_counter = nullptr; // tie refolds are a few per million rays: counted where they happen, not in a lane register
     __device__ __forceinline__ void node() {}
     __device__ __forceinline__ void tri() {}
     __device__ __forceinline__ void sphere() {}
     __device__ __forceinline__ void ray() { rays++; }
-    __device__ __forceinline__ void refold() { refolds++; }
+    __device__ __forceinline__ void refold() { atomicAdd(refold_counter, 1ull); }
     __device__ __forceinline__ void shade() {}
 };
 
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
     LdsStack stack;
     stack.init(lds_stack + lane);
     typename std::conditional<COUNT_WORK, RegCounters<SS>, RayCounters<SS>>::type cnt;
+    cnt.refold_counter = counters + 4;
 
     uint32_t q = NO_PIXEL, ij = 0, pixel = 0; // ij = column | row << 16 of the pixel (both < 65536)
     f3 col = mk3(0.0f, 0.0f, 0.0f);
@@ -489,9 +492,10 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
         }
     }
 
-    const uint32_t rays = rays_wave, refolds = wave_sum(cnt.refolds);
+    uint32_t refolds = 0;
+    if constexpr (COUNT_WORK) refolds = wave_sum(cnt.refolds);
     if (lane == 0) {
-        atomicAdd(&counters[0], (unsigned long long)rays);
+        atomicAdd(&counters[0], (unsigned long long)rays_wave);
         if (refolds) atomicAdd(&counters[4], (unsigned long long)refolds);
     }
     if constexpr (COUNT_WORK) {
@@ -631,6 +635,7 @@ __global__ __launch_bounds__(64 * W) void render_pool_kernel(SceneView sc, Camer
     Pool<P> pool;
     pool.f = lds_pool;
     typename std::conditional<COUNT_WORK, RegCounters<true>, RayCounters<true>>::type cnt;
+    cnt.refold_counter = counters + 4;
     uint32_t wc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     unsigned long long t_start = 0;
     if constexpr (COUNT_WORK) t_start = wall_clock64();
@@ -839,7 +844,9 @@ __global__ __launch_bounds__(64 * W) void render_pool_kernel(SceneView sc, Camer
         if (n_walk == 0 && popc64(__ballot(my >= 0)) == 0) break; // nothing listed, nothing walking, nothing to retire
     }
 
-    const uint32_t rays = wave_sum(cnt.rays), refolds = wave_sum(cnt.refolds);
+    const uint32_t rays = wave_sum(cnt.rays);
+    uint32_t refolds = 0;
+    if constexpr (COUNT_WORK) refolds = wave_sum(cnt.refolds);
     if (lane == 0) {
         atomicAdd(&counters[0], (unsigned long long)rays);
         if (refolds) atomicAdd(&counters[4], (unsigned long long)refolds);
