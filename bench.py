@@ -41,6 +41,8 @@ WORKLOADS = {
 # /opt/skills/guides/MI355X_MICROARCH.md: 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (= the 157.3 TFLOP/s fp32 spec / 2)
 VALU_PEAK_TLANEOPS_256CU = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
+L2_PEAK_GBS = 34500.0          # aggregate L2, same guide
+INFINITY_CACHE_GATHER_GBS = 8600.0  # random 1 KB-row gathers from a 38 MB table (Infinity Cache resident), same guide
 DEFAULT_CHUNKS = 32  # same for every N: 1/8 of the frame per rank needs fine units (tools/rank_share.py), the whole frame does not mind
 
 
@@ -56,15 +58,23 @@ def algorithmic_bytes(st, width, height):
 def pmc_traffic(workload, world):
     """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/run_rocprof.sh: FETCH_SIZE and WRITE_SIZE in their own runs; tools/summarize_prof.py applies the guide's
-    unit and gfx950 corrections).  Only valid for the default 1-GPU workload; otherwise None."""
-    if workload != "cats" or world != 1:
+    unit and gfx950 corrections): the newest profiles/<dir>/pmc_render_kernel.json whose bench line was this workload on
+    one GPU.  None when there is none."""
+    if world != 1:
         return None
     root = os.path.join(REPO, "profiles")
     best = None
     for name in sorted(os.listdir(root)) if os.path.isdir(root) else []:
         f = os.path.join(root, name, "pmc_render_kernel.json")
-        if os.path.isfile(f):
-            best = f
+        b = os.path.join(root, name, "bench.json")
+        if not (os.path.isfile(f) and os.path.isfile(b)):
+            continue
+        try:
+            cfg = json.load(open(b))
+            if cfg.get("n_gpus") == 1 and cfg["config"]["workload"].split()[0] == workload:
+                best = f
+        except (KeyError, ValueError, OSError, IndexError):
+            continue
     if not best:
         return None
     try:
@@ -165,10 +175,17 @@ def main():
         finish()
     frame.drain()
     barrier()
-    # Nothing inside the timed region waits on the host.
+    # Nothing inside the timed region waits on the host.  An event behind each frame's render (on its render stream) gives
+    # the per-step kernel figure: with two frames in flight a dispatch's own begin-to-end time includes its wait for the
+    # previous frame's wave slots, what counts is how far apart consecutive frames END.
+    ends = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         launch()
+        ev = torch.cuda.Event(enable_timing=True)
+        cur = frame._current[1] if frame._current is not None else None
+        ev.record(cur if cur is not None else torch.cuda.current_stream(device))
+        ends.append(ev)
         finish()
     frame.drain()  # every one of the K frames is assembled (tile: on every rank; sample: on rank 0) inside the timed region
     barrier()
@@ -184,13 +201,15 @@ def main():
         kernel_ms.append(st.kernel_ms)
         rays_local = st.rays  # deterministic: the same frame again
 
-    t = torch.tensor([elapsed, float(rays_local), sum(kernel_ms) / max(len(kernel_ms), 1)], dtype=torch.float64, device=device)
+    # mean distance between the ends of consecutive frames' render work (kernel + chunk-sum pass) inside the timed region
+    end_to_end_ms = (ends[0].elapsed_time(ends[-1]) / (len(ends) - 1)) if len(ends) > 1 else float("nan")
+    t = torch.tensor([elapsed, float(rays_local), sum(kernel_ms) / max(len(kernel_ms), 1), end_to_end_ms], dtype=torch.float64, device=device)
     if world > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed, rays_frame, kernel_avg_ms = float(tmax[0]), float(tsum[1]), float(tmax[2])
+        elapsed, rays_frame, kernel_avg_ms, end_to_end_ms = float(tmax[0]), float(tsum[1]), float(tmax[2]), float(tmax[3])
     else:
         rays_frame, kernel_avg_ms = float(rays_local), float(t[2])
 
@@ -207,25 +226,39 @@ def main():
         ksec = kernel_avg_ms / 1e3
         ops = lane_ops(stw)
         traffic = pmc_traffic(args.workload, world)
-        abytes = algorithmic_bytes(stw, W, H) if args.mode == "tile" else algorithmic_bytes(stw, W, H)
+        abytes = algorithmic_bytes(stw, W, H)
+        used_chunks = chunks if args.mode == "tile" else frame.sample_chunks
         out = {
             "metric": "Mrays/s (all bounces)", "value": rays_frame * args.steps / elapsed / 1e6, "unit": "Mrays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d %dspp depth %d (models/%s + ground + emissive sphere, seed %d)" %
                        (args.workload, W, H, spp, depth, {"cats": "cats.obj", "random_spheres": "no mesh"}.get(builder, "cat.obj"), seed),
-                       "partition": "%s x%d" % (args.mode, world), "frames_in_flight": frame.slots.in_flight, "sample_chunks": chunks if args.mode == "tile" else frame.sample_chunks, "triangles": info.num_triangles, "bvh_nodes": info.num_nodes,
+                       "partition": "%s x%d" % (args.mode, world), "frames_in_flight": frame.slots.in_flight, "sample_chunks": used_chunks,
+                       "image": ("chunked-sum variant: same samples, each pixel's %d chunk sums added in chunk order; differs from the reference's "
+                                 "sequential sample-order sum by float association only (<= 3e-7 relative, tests/test_gpu.py); --chunks 1 is the bit-exact one"
+                                 % used_chunks) if used_chunks > 1 else "bit-exact: every pixel's samples summed in sample order (renderer.h:28-32)",
+                       "triangles": info.num_triangles, "bvh_nodes": info.num_nodes, "bvh_depth": info.bvh_depth,
                        "rays_per_frame": int(rays_frame), "device_cus": cus},
             "roofline": {"bound": "valu", "achieved": ops / ksec / 1e12, "peak": valu_peak, "unit": "Tlane-op/s",
                          "frac": ops / ksec / 1e12 / valu_peak, "traffic": traffic,
-                         "kernel": "render_kernel", "kernel_ms": kernel_avg_ms, "kernel_ms_note": "mean of 3 launches that run alone, right after the timed region", "rays_per_launch": int(stw.rays),
+                         "kernel": "render_kernel", "kernel_ms": kernel_avg_ms, "kernel_ms_note": "mean of 3 launches that run alone, right after the timed region",
+                         "per_step": {"kernel_end_to_end_ms": end_to_end_ms, "frac": ops / (end_to_end_ms / 1e3) / 1e12 / valu_peak,
+                                      "note": "mean distance between the ends of consecutive frames' render work in the timed region (HIP events on the "
+                                              "render streams): what a frame costs with %d frames in flight; <= ms_per_step" % frame.slots.in_flight},
+                         "rays_per_launch": int(stw.rays), "lane_ops_per_launch": ops,
                          "nodes_per_ray": stw.nodes / max(stw.rays, 1), "tri_tests_per_ray": stw.tri_tests / max(stw.rays, 1),
+                         "sphere_tests_per_ray": stw.sphere_tests / max(stw.rays, 1), "shaded_hits_per_ray": stw.shaded_hits / max(stw.rays, 1),
                          "hbm": {"bound": "hbm", "achieved": (traffic / ksec / 1e9) if traffic else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": (traffic / ksec / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                                 "algorithmic_request_GBps": abytes / ksec / 1e9,
-                                 "note": "achieved = PMC HBM bytes per launch (traffic) / kernel time: the scene (%d KiB) is cache resident, "
-                                         "so the algorithmic node+triangle+sphere+framebuffer bytes are a request rate served by L1/L2, not HBM traffic"
-                                         % ((info.node_bytes + info.triangle_bytes + info.sphere_bytes) // 1024)}},
+                                 "algorithmic_bytes_per_launch": abytes,
+                                 "note": "achieved = PMC HBM bytes per launch (traffic) / kernel time; the algorithmic bytes are priced in l2_lds"},
+                         "l2_lds": {"bound": "l2", "achieved": abytes / ksec / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": abytes / ksec / 1e9 / L2_PEAK_GBS,
+                                    "infinity_cache_gather_peak": INFINITY_CACHE_GATHER_GBS, "frac_of_infinity_cache_gather": abytes / ksec / 1e9 / INFINITY_CACHE_GATHER_GBS,
+                                    "note": "algorithmic node (64 B) + triangle (48 B) + sphere (32 B) + framebuffer bytes / kernel time: a request rate served by the "
+                                            "LDS node copy, L1 and L2 when the scene (%d KiB) is cache resident; for scenes beyond L2 (the 1 M-triangle grid) the "
+                                            "Infinity-Cache gather rate is the memory-side bound"
+                                            % ((info.node_bytes + info.triangle_bytes + info.sphere_bytes) // 1024)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(desc, cam_params, W, H, depth, seed)

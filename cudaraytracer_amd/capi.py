@@ -16,7 +16,10 @@ CRT_OK, CRT_ERR_INVALID, CRT_ERR_IO, CRT_ERR_HIP, CRT_ERR_LIMIT, CRT_ERR_NO_DEVI
 TEX_SOLID, TEX_CHECKER = 0, 1
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIFFUSE_LIGHT, MAT_DIELECTRIC = 0, 1, 2, 3
 BUILD_GPU_LBVH = 1
-OUT_ACCUM, OUT_COMPACT, COUNT_WORK = 1, 2, 4
+OUT_ACCUM, OUT_COMPACT, COUNT_WORK, OUT_DEVICE = 1, 2, 4, 8
+MULTI_TILE, MULTI_SAMPLE = 0, 1
+# tests set this: re-read the CRT_* tuning knobs before every render (the library reads them at commit only)
+RELOAD_TUNING_EACH_RENDER = False
 DEVICE_NONE = -1
 NO_TEXTURE = 0xFFFFFFFF
 
@@ -59,8 +62,8 @@ class SceneInfo(C.Structure):  # crt_scene_info
 
 # every symbol include/crt.h declares (tests check that the library exports exactly these)
 SYMBOLS = ["crt_last_error", "crt_version", "crt_load_obj", "crt_load_obj_ex", "crt_free", "crt_scene_create", "crt_scene_destroy", "crt_scene_add_texture",
-           "crt_scene_add_material", "crt_scene_add_mesh", "crt_scene_add_sphere", "crt_scene_commit", "crt_scene_commit_ex", "crt_scene_get_info",
-           "crt_scene_get_ranks", "crt_camera_init", "crt_render", "crt_compact_floats", "crt_untile", "crt_finalize", "crt_quantize_rgb8", "crt_write_png"]
+           "crt_scene_add_material", "crt_scene_add_mesh", "crt_scene_add_sphere", "crt_scene_commit", "crt_scene_commit_ex", "crt_scene_commit_devices", "crt_scene_reload_tuning", "crt_scene_get_info",
+           "crt_scene_get_ranks", "crt_camera_init", "crt_render", "crt_render_multi", "crt_compact_floats", "crt_untile", "crt_finalize", "crt_quantize_rgb8", "crt_write_png"]
 
 _lib = None
 
@@ -95,10 +98,13 @@ def bind(L):
     L.crt_scene_add_sphere.argtypes = [C.c_void_p, f3, C.c_float, C.c_uint32]
     L.crt_scene_commit.argtypes = [C.c_void_p, C.c_int]
     L.crt_scene_commit_ex.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+    L.crt_scene_commit_devices.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_uint32, C.c_uint32]
+    L.crt_scene_reload_tuning.argtypes = [C.c_void_p]
     L.crt_scene_get_info.argtypes = [C.c_void_p, C.POINTER(SceneInfo)]
     L.crt_scene_get_ranks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.crt_camera_init.argtypes = [C.POINTER(Camera), C.c_uint32, f3, f3, f3, C.c_float, C.c_float, C.c_float, C.c_float]
     L.crt_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    L.crt_render_multi.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     L.crt_compact_floats.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     L.crt_compact_floats.restype = C.c_uint64
     L.crt_untile.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
@@ -183,6 +189,14 @@ class Scene:
         else:
             _check(self._L.crt_scene_commit_ex(self._h, device, flags), self._L)
 
+    def commit_devices(self, devices, flags=0):
+        """crt_scene_commit_devices: one copy of the scene per logical rank (the same device may be listed more than once)."""
+        arr = (C.c_int * len(devices))(*devices)
+        _check(self._L.crt_scene_commit_devices(self._h, arr, len(devices), flags), self._L)
+
+    def reload_tuning(self):
+        _check(self._L.crt_scene_reload_tuning(self._h), self._L)
+
     def info(self):
         info = SceneInfo()
         _check(self._L.crt_scene_get_info(self._h, C.byref(info)), self._L)
@@ -196,8 +210,9 @@ class Scene:
         return out
 
     def render(self, cam, width, height, spp, max_depth=10, seed=1984, sample_offset=0, ids_sample=0, tile_rank=0, tile_ranks=1,
-               flags=0, out_rgb=None, out_ids=None, want_ids=False, want_stats=True, stream=None, sample_chunks=0):
-        """crt_render.  out_rgb / out_ids: numpy arrays (host) or integer device addresses; None allocates numpy outputs."""
+               flags=0, out_rgb=None, out_ids=None, want_ids=False, want_stats=True, stream=None, sample_chunks=0, multi=None):
+        """crt_render (multi = MULTI_TILE / MULTI_SAMPLE: crt_render_multi over the devices of commit_devices).
+        out_rgb / out_ids: numpy arrays (host) or integer device addresses; None allocates numpy outputs."""
         p = RenderParams(width=width, height=height, spp=spp, sample_offset=sample_offset, max_depth=max_depth, tile_rank=tile_rank,
                          tile_ranks=tile_ranks, flags=flags, ids_sample=ids_sample, sample_chunks=sample_chunks, seed=seed, stream=stream)
         L = self._L
@@ -212,7 +227,12 @@ class Scene:
         rgb_ptr = out_rgb.ctypes.data if isinstance(out_rgb, np.ndarray) else out_rgb
         ids_ptr = (out_ids.ctypes.data if isinstance(out_ids, np.ndarray) else out_ids) if out_ids is not None else None
         st = Stats() if want_stats else None
-        _check(L.crt_render(self._h, C.byref(cam), C.byref(p), rgb_ptr, ids_ptr, C.byref(st) if st is not None else None), L)
+        if RELOAD_TUNING_EACH_RENDER:
+            self.reload_tuning()
+        if multi is None:
+            _check(L.crt_render(self._h, C.byref(cam), C.byref(p), rgb_ptr, ids_ptr, C.byref(st) if st is not None else None), L)
+        else:
+            _check(L.crt_render_multi(self._h, C.byref(cam), C.byref(p), multi, rgb_ptr, ids_ptr, C.byref(st) if st is not None else None), L)
         if rgb_np is not None and not (flags & OUT_COMPACT):
             rgb_np = rgb_np.reshape(height, width, 3)
         if ids_np is not None:

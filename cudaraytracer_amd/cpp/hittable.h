@@ -2,6 +2,8 @@
 // never looks inside.  Here Hittable is the owner of the library's scene handle.
 #pragma once
 
+#include <vector>
+
 #include "utility.h"
 
 class Hittable {
@@ -11,4 +13,5 @@ public:
     Hittable(const Hittable &) = delete;
     Hittable &operator=(const Hittable &) = delete;
     crt_scene *scene;
+    std::vector<int> devices; // HIP devices the scene was committed to with crt_scene_commit_devices (empty: one device, crt_scene_commit)
 };

@@ -3,6 +3,8 @@
 // No per-pixel RNG state is allocated: the Philox streams are keyed on (pixel, sample, bounce).
 #pragma once
 
+#include <vector>
+
 #include "camera.h"
 
 class Renderer {
@@ -16,6 +18,12 @@ public:
     uint64_t seed = 1984;     // renderer.h:45
     uint32_t sample_chunks = 0; // 0: each pixel's samples summed in order by one lane (renderer.h:28-32, bit-exact);
                                 // a power of two dividing spp: finer work units, chunk sums added in order (include/crt.h)
+    // More than one GPU (new; the reference's launch_kernel_render drives one, renderer.h:64-73): the HIP devices that share
+    // the frame, one logical rank each -- 8x8 tiles dealt round robin and gathered (CRT_MULTI_TILE, bitwise the one-GPU
+    // frame) or the samples split and the float sums reduced (CRT_MULTI_SAMPLE) over RCCL.  Empty: one device.  A world
+    // committed to other devices is committed again to these.
+    std::vector<int> devices;
+    int multi_mode = CRT_MULTI_TILE;
     crt_stats last_stats{};
 
     // framebuffer: width*height vec3, host memory (the reference passes managed memory, kernel.cu:60) or a HIP device pointer
@@ -29,7 +37,15 @@ public:
         cam.background[0] = (*d_camera)->background.x; // Camera::background is a public member (camera.h:23)
         cam.background[1] = (*d_camera)->background.y;
         cam.background[2] = (*d_camera)->background.z;
-        checkCrtErrors(crt_render((*d_world)->scene, &cam, &p, &framebuffer[0].x, nullptr, &last_stats));
+        if (devices.empty()) {
+            checkCrtErrors(crt_render((*d_world)->scene, &cam, &p, &framebuffer[0].x, nullptr, &last_stats));
+            return;
+        }
+        if ((*d_world)->devices != devices) {
+            checkCrtErrors(crt_scene_commit_devices((*d_world)->scene, devices.data(), (uint32_t)devices.size(), 0));
+            (*d_world)->devices = devices;
+        }
+        checkCrtErrors(crt_render_multi((*d_world)->scene, &cam, &p, multi_mode, &framebuffer[0].x, nullptr, &last_stats));
     }
 
 private:

@@ -15,6 +15,9 @@ public:
     // reference: declared at scene.h:25, never defined; here it selects the OBJ files launch_triangles_scene() loads
     void load_models(const std::vector<std::string> &modelPaths) { model_paths = modelPaths; }
     int device = 0;
+    // More than one GPU (new; the reference is single-GPU): the HIP devices the scene is replicated to, one per logical
+    // rank of Renderer's tile / sample partition (crt_scene_commit_devices).  Empty: `device` alone.
+    std::vector<int> devices;
     // false (reference, scene.h:147-148): every triangle Lambertian(0.7, 0.3, 0.16).  true (row N4): each part of a model
     // gets its .mtl material -- DiffuseLight(Ke) when it emits, else Lambertian(Kd).
     bool materials_from_mtl = false;
@@ -48,7 +51,7 @@ public:
         checkCrtErrors(crt_scene_add_sphere(world->scene, ground_c, 1000.0f, ground_mat));
         checkCrtErrors(crt_scene_add_sphere(world->scene, light_c, 2.0f, light_mat));
         printf("- Scene Created with %d objects\n", num_triangles + 2); // scene.h:175
-        checkCrtErrors(crt_scene_commit(world->scene, device));
+        commit(world);
         printf("- BVH constructed\n"); // bvh.h:184
         *d_world = world;
     }
@@ -97,11 +100,19 @@ public:
         add(-4.0f, 1.0f, 0.0f, 1.0f, CRT_MAT_LAMBERTIAN, 0.4f, 0.2f, 0.1f, 0.0f);
         add(4.0f, 1.0f, 0.0f, 1.0f, CRT_MAT_METAL, 0.7f, 0.6f, 0.5f, 0.0f);
         printf("- Scene Created with %u objects\n", n);
-        checkCrtErrors(crt_scene_commit(world->scene, device));
+        commit(world);
         printf("- BVH constructed\n"); // bvh.h:184
         *d_world = world;
     }
 
 private:
+    void commit(Hittable *world)
+    {
+        if (devices.empty()) checkCrtErrors(crt_scene_commit(world->scene, device));
+        else {
+            checkCrtErrors(crt_scene_commit_devices(world->scene, devices.data(), (uint32_t)devices.size(), 0));
+            world->devices = devices;
+        }
+    }
     std::vector<std::string> model_paths;
 };

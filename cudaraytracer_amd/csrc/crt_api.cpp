@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <utility>
 #include <vector>
@@ -19,6 +20,8 @@
 #include "crt_kernels.h"
 #include "crt_lbvh.h"
 #include <chrono>
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and prototypes only: the library is loaded with dlopen on first multi-device use
 
 using namespace crt;
 
@@ -225,33 +228,53 @@ extern "C" int crt_load_obj(const char *path, float **xyz_nrm, uint32_t *nverts,
 // ---------------------------------------------------------------------------------------------------------
 // scene
 // ---------------------------------------------------------------------------------------------------------
-struct crt_scene {
-    std::vector<HostTriangle> tris;
-    std::vector<HostSphere> spheres;
-    std::vector<Material> mats;
-    std::vector<Texture> texs;
-    // prepared (host: ranks + BVH) / committed (device buffers)
-    bool prepared = false;
-    bool committed = false;
+static int get_env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+namespace crt_detail {
+// Tuning knobs, read from the environment when a scene is committed (and by crt_scene_reload_tuning), not per frame.
+struct Tuning {
+    int kernel = 0;            // CRT_KERNEL: 0 render_kernel (pixel per lane), 1 render_pool_kernel (whole-pixel frames only)
+    int pool_refill = 16;      // CRT_POOL_REFILL: pool kernel, free lanes that end a run of walk steps
+    int sched_threshold = 44;  // CRT_SCHED_THRESHOLD: lanes that must wait for the shade phase before it runs
+    int node_cache = 1;        // CRT_NODE_CACHE: LDS copy of the top of the tree: 0 never, 1 when the frame fills the GPU, 2 always
+    int stripe_bands = 1;      // CRT_STRIPE_BANDS: each block counter owns a contiguous band of the frame
+    int waves_per_cu = 20;     // CRT_WAVES_PER_CU: persistent waves launched per compute unit (96 VGPRs: 5 per SIMD)
+    int print_sections = 0;    // CRT_PRINT_SECTIONS: with CRT_COUNT_WORK and stats, print the section clocks
+    void from_env()
+    {
+        kernel = get_env_int("CRT_KERNEL", 0) == 1 ? 1 : 0;
+        pool_refill = std::min(std::max(get_env_int("CRT_POOL_REFILL", 16), 1), 63);
+        sched_threshold = std::min(std::max(get_env_int("CRT_SCHED_THRESHOLD", 44), 1), 64);
+        node_cache = std::min(std::max(get_env_int("CRT_NODE_CACHE", 1), 0), 2);
+        stripe_bands = get_env_int("CRT_STRIPE_BANDS", 1) ? 1 : 0;
+        waves_per_cu = std::min(std::max(get_env_int("CRT_WAVES_PER_CU", 20), 1), 64);
+        print_sections = get_env_int("CRT_PRINT_SECTIONS", 0);
+    }
+};
+
+// Per-stream scratch of one device: work counters, sample-chunk slabs (grow only: chunks x frame floats, summed in chunk
+// order by finalize_chunks_kernel), the staging buffers of host-pointer renders (grow only) and the timing events.  Calls
+// on one stream are ordered and share a set; calls on different streams get different sets, so their kernels may overlap
+// (the next frame fills the GPU while this one's last waves drain) and two host-pointer renders never share staging.
+struct StreamScratch {
+    hipStream_t stream = nullptr; bool used = false, recorded = false; uint64_t last_use = 0;
+    unsigned long long *d_counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr; // around the render kernel; after the last use of the set
+    float *d_chunk_slabs = nullptr; size_t chunk_slab_floats = 0;
+    float *d_stage_rgb = nullptr; size_t stage_rgb_floats = 0;
+    int *d_stage_ids = nullptr; size_t stage_ids = 0;
+};
+
+// One copy of the committed scene on one HIP device.
+struct DeviceScene {
     int device = -1;
-    std::vector<uint32_t> rank;
-    FlatBvh bvh;
-    std::vector<Shade> shades; // materials joined with their textures (device record)
-    std::vector<q4> normals;   // per triangle slot: unit normal + primitive id (crt_traverse.h: triangle_normal)
-    uint32_t builder = 0; float build_ms = 0.0f;
-    std::vector<Sphere> flat_spheres; // the spheres that are tested before the walk (the others are slots of the tree)
     void *d_nodes = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_shades = nullptr, *d_normals = nullptr;
-    uint32_t max_waves = 0; // persistent-grid size: compute units x wave slots
+    uint32_t cus = 0; // compute units: the persistent grid is cus x Tuning::waves_per_cu waves
     SceneView view{};
-    // Per-stream scratch: work counters, sample-chunk slabs (grow only: chunks x frame floats, summed in chunk order by
-    // finalize_chunks_kernel) and the timing events.  Calls on one stream are ordered and share a set; calls on different
-    // streams get different sets, so their kernels may overlap (the next frame fills the GPU while this one's last waves drain).
-    struct StreamScratch {
-        hipStream_t stream = nullptr; bool used = false, recorded = false; uint64_t last_use = 0;
-        unsigned long long *d_counters = nullptr;
-        hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr; // around the render kernel; after the last use of the set
-        float *d_chunk_slabs = nullptr; size_t chunk_slab_floats = 0;
-    };
     static constexpr int MAX_STREAMS = 4;
     StreamScratch scratch[MAX_STREAMS];
     uint64_t use_clock = 0;
@@ -271,25 +294,76 @@ struct crt_scene {
         pick->used = true; pick->stream = stream; pick->last_use = ++use_clock;
         return pick;
     }
-    // staging for host-pointer renders (grow only)
-    float *d_stage_rgb = nullptr; size_t stage_rgb_floats = 0;
-    int *d_stage_ids = nullptr; size_t stage_ids = 0;
-
-    void release_device()
+    void release()
     {
         if (device >= 0) (void)hipSetDevice(device);
-        void *ptrs[] = { d_nodes, d_tris, d_spheres, d_shades, d_normals, d_stage_rgb, d_stage_ids };
+        void *ptrs[] = { d_nodes, d_tris, d_spheres, d_shades, d_normals };
         for (void *p : ptrs) if (p) (void)hipFree(p);
-        d_nodes = d_tris = d_spheres = d_shades = d_normals = nullptr; d_stage_rgb = nullptr; d_stage_ids = nullptr;
-        stage_rgb_floats = stage_ids = 0;
+        d_nodes = d_tris = d_spheres = d_shades = d_normals = nullptr;
         for (StreamScratch &x : scratch) {
             if (x.d_counters) (void)hipFree(x.d_counters);
             if (x.d_chunk_slabs) (void)hipFree(x.d_chunk_slabs);
+            if (x.d_stage_rgb) (void)hipFree(x.d_stage_rgb);
+            if (x.d_stage_ids) (void)hipFree(x.d_stage_ids);
             if (x.ev0) (void)hipEventDestroy(x.ev0);
             if (x.ev1) (void)hipEventDestroy(x.ev1);
             if (x.ev_done) (void)hipEventDestroy(x.ev_done);
             x = StreamScratch();
         }
+        device = -1;
+    }
+};
+
+// crt_render_multi's per-rank state: two sets of {render stream, local part, events} that consecutive frames alternate
+// between, and on the root the gathered parts and the end-of-frame events.
+struct MultiRank {
+    hipStream_t stream[2] = { nullptr, nullptr };
+    float *d_local[2] = { nullptr, nullptr }; size_t local_floats = 0; // compact tile list (tile mode) or raw sums (sample mode)
+    float *d_all[2] = { nullptr, nullptr }; size_t all_floats = 0;      // the n parts back to back: on the root, and on every rank for ncclAllGather
+    hipEvent_t sent[2] = { nullptr, nullptr };                          // copy transport: this rank's part has reached the root
+    bool sent_recorded[2] = { false, false };
+    void *comm = nullptr;                                               // ncclComm_t (RCCL transport)
+};
+struct MultiState {
+    bool ready = false, use_rccl = false, peer_ids = false;
+    std::vector<MultiRank> rank;
+    float *d_stage_rgb = nullptr; size_t stage_rgb_floats = 0;          // root: staging of host-pointer frames
+    int *d_stage_ids = nullptr; size_t stage_ids = 0;
+    hipEvent_t frame_done[2] = { nullptr, nullptr }; bool done_recorded[2] = { false, false };
+    hipEvent_t fork = nullptr;                                          // the caller's stream at the start of a frame
+    uint64_t frames = 0;
+};
+} // namespace crt_detail
+using namespace crt_detail;
+
+struct crt_scene {
+    std::vector<HostTriangle> tris;
+    std::vector<HostSphere> spheres;
+    std::vector<Material> mats;
+    std::vector<Texture> texs;
+    // prepared (host: ranks + BVH) / committed (device buffers)
+    bool prepared = false;
+    bool committed = false;
+    int device = -1; // = dev[0].device
+    std::vector<uint32_t> rank;
+    FlatBvh bvh;
+    std::vector<Shade> shades; // materials joined with their textures (device record)
+    std::vector<q4> normals;   // per triangle slot: unit normal + primitive id (crt_traverse.h: triangle_normal)
+    uint32_t builder = 0; float build_ms = 0.0f;
+    std::vector<Sphere> flat_spheres; // the spheres that are tested before the walk (the others are slots of the tree)
+    bool sphere_slots = false;        // some spheres went into the tree
+    Tuning tuning;
+    std::vector<DeviceScene> dev;     // dev[0]: the copy crt_render uses; one per logical rank after crt_scene_commit_devices
+    MultiState multi;
+    std::mutex mutex;                 // crt_render's bookkeeping (scratch sets, staging): calls on different streams may come from different threads
+
+    void release_multi();
+    void release_device()
+    {
+        release_multi();
+        for (DeviceScene &d : dev) d.release();
+        dev.clear();
+        device = -1;
         committed = false;
     }
 };
@@ -374,12 +448,6 @@ extern "C" int crt_scene_add_sphere(crt_scene *s, const float center[3], float r
     return CRT_OK;
 }
 
-static int get_env_int(const char *name, int dflt)
-{
-    const char *v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
-
 template <class T>
 static int upload(void **dst, const std::vector<T> &v)
 {
@@ -448,16 +516,18 @@ extern "C" int crt_scene_commit(crt_scene *s, int device)
     return crt_scene_commit_ex(s, device, (b && strcmp(b, "lbvh") == 0) ? (uint32_t)CRT_BUILD_GPU_LBVH : 0u);
 }
 
-extern "C" int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags)
+// Host side of a commit: ranks, tree, shading records, normals (with CRT_BUILD_GPU_LBVH ranks and tree come from
+// `build_device`).  Leaves s->prepared set.
+static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
 {
-    if (!s) return fail(CRT_ERR_INVALID, "crt_scene_commit: null scene");
     if (s->tris.empty() && s->spheres.empty()) return fail(CRT_ERR_INVALID, "crt_scene_commit: empty scene");
     s->release_device();
     s->prepared = false;
+    s->tuning.from_env();
 
     const uint32_t max_leaf = (uint32_t)get_env_int("CRT_MAX_LEAF", 2);
     s->builder = 0; s->build_ms = 0.0f;
-    const bool gpu_built = (flags & CRT_BUILD_GPU_LBVH) && commit_gpu_lbvh(s, device, std::min(std::max(max_leaf, 1u), 8u));
+    const bool gpu_built = (flags & CRT_BUILD_GPU_LBVH) && commit_gpu_lbvh(s, build_device, std::min(std::max(max_leaf, 1u), 8u));
     const auto host_t0 = std::chrono::steady_clock::now();
     if (!gpu_built) {
         // reference order: all triangles, then all spheres (scene.h:161-165)
@@ -495,7 +565,7 @@ extern "C" int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags)
         }
     }
     if (flat.size() > 4096) return fail(CRT_ERR_LIMIT, "crt_scene_commit: more than 4096 spheres outside the tree");
-    const std::vector<Sphere> &spheres = flat;
+    s->sphere_slots = !tree_spheres.empty();
 
     if (!gpu_built) {
         build_bvh(s->tris, s->rank, tree_spheres, max_leaf, s->bvh);
@@ -531,33 +601,53 @@ extern "C" int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags)
             else s->normals[k] = triangle_normal(tp[0], tp[1], tp[2]);
         }
     }
-
     s->prepared = true;
-    if (device == CRT_DEVICE_NONE) return CRT_OK; // host-side preparation only (ranks, BVH); rendering stays unavailable
+    return CRT_OK;
+}
 
+// Device side of a commit: one copy of the prepared scene on `device`.
+static int upload_replica(crt_scene *s, DeviceScene &d, int device)
+{
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(CRT_ERR_NO_DEVICE, "crt_scene_commit: no such HIP device");
     HIP_TRY(hipSetDevice(device));
-    s->device = device;
+    d.device = device;
     int rc;
-    if ((rc = upload(&s->d_nodes, s->bvh.nodes))) return rc;
-    if ((rc = upload(&s->d_tris, s->bvh.tris))) return rc;
-    if ((rc = upload(&s->d_spheres, spheres))) return rc;
-    if ((rc = upload(&s->d_shades, s->shades))) return rc;
-    if ((rc = upload(&s->d_normals, s->normals))) return rc;
-    {
-        hipDeviceProp_t prop;
-        HIP_TRY(hipGetDeviceProperties(&prop, device));
-        // 20 = the waves of the render kernel a compute unit holds (96 VGPRs: 5 per SIMD); more would only queue up behind them
-        s->max_waves = (uint32_t)prop.multiProcessorCount * (uint32_t)std::min(std::max(get_env_int("CRT_WAVES_PER_CU", 20), 1), 64);
-    }
-    SceneView &v = s->view;
-    v.nodes = (const q4 *)s->d_nodes; v.tris = (const q4 *)s->d_tris; v.spheres = (const Sphere *)s->d_spheres;
-    v.shades = (const Shade *)s->d_shades; v.normals = (const q4 *)s->d_normals;
-    v.root_ref = s->bvh.root_ref; v.nnodes = (uint32_t)(s->bvh.nodes.size() / 4); v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size(); v.sphere_slots = tree_spheres.empty() ? 0u : 1u;
+    if ((rc = upload(&d.d_nodes, s->bvh.nodes))) return rc;
+    if ((rc = upload(&d.d_tris, s->bvh.tris))) return rc;
+    if ((rc = upload(&d.d_spheres, s->flat_spheres))) return rc;
+    if ((rc = upload(&d.d_shades, s->shades))) return rc;
+    if ((rc = upload(&d.d_normals, s->normals))) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    d.cus = (uint32_t)prop.multiProcessorCount;
+    SceneView &v = d.view;
+    v.nodes = (const q4 *)d.d_nodes; v.tris = (const q4 *)d.d_tris; v.spheres = (const Sphere *)d.d_spheres;
+    v.shades = (const Shade *)d.d_shades; v.normals = (const q4 *)d.d_normals;
+    v.root_ref = s->bvh.root_ref; v.nnodes = (uint32_t)(s->bvh.nodes.size() / 4); v.ntris = (uint32_t)(s->bvh.tris.size() / 3);
+    v.nspheres = (uint32_t)s->flat_spheres.size(); v.sphere_slots = s->sphere_slots ? 1u : 0u;
     v.root_min = s->bvh.root_box.mn; v.root_max = s->bvh.root_box.mx;
+    return CRT_OK;
+}
+
+extern "C" int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags)
+{
+    if (!s) return fail(CRT_ERR_INVALID, "crt_scene_commit: null scene");
+    int rc = prepare_host(s, device, flags);
+    if (rc) return rc;
+    if (device == CRT_DEVICE_NONE) return CRT_OK; // host-side preparation only (ranks, BVH); rendering stays unavailable
+    s->dev.resize(1);
+    if ((rc = upload_replica(s, s->dev[0], device))) { s->release_device(); return rc; }
+    s->device = device;
     s->committed = true;
+    return CRT_OK;
+}
+
+extern "C" int crt_scene_reload_tuning(crt_scene *s)
+{
+    if (!s) return fail(CRT_ERR_INVALID, "crt_scene_reload_tuning: null scene");
+    s->tuning.from_env();
     return CRT_OK;
 }
 
@@ -647,23 +737,77 @@ extern "C" uint64_t crt_compact_floats(uint32_t width, uint32_t height, uint32_t
     return ((ntiles + tile_ranks - 1) / tile_ranks) * 64u * 3u;
 }
 
-extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_render_params *p, float *out_rgb, int32_t *out_ids, crt_stats *stats)
+// ---------------------------------------------------------------------------------------------------------
+// what crt_render, crt_render_noalloc and crt_render_multi share
+// ---------------------------------------------------------------------------------------------------------
+static int check_render_params(const crt_scene *s, const crt_camera *cam, const crt_render_params *p, const void *out_rgb, const char *who, uint32_t *chunks_out)
 {
-    crt_scene *s = const_cast<crt_scene *>(cs);
-    if (!s || !cam || !p || !out_rgb) return fail(CRT_ERR_INVALID, "crt_render: null argument");
-    if (!s->committed) return fail(s->prepared ? CRT_ERR_NO_DEVICE : CRT_ERR_INVALID, "crt_render: scene not committed to a HIP device");
-    if (p->width == 0 || p->height == 0 || p->spp == 0) return fail(CRT_ERR_INVALID, "crt_render: empty frame or zero samples");
-    if (p->tile_ranks == 0 || p->tile_rank >= p->tile_ranks) return fail(CRT_ERR_INVALID, "crt_render: tile_rank must be < tile_ranks");
-    if ((uint64_t)p->width * p->height > (1ull << 31)) return fail(CRT_ERR_LIMIT, "crt_render: more than 2^31 pixels");
+    const std::string w(who);
+    if (!s || !cam || !p || !out_rgb) return fail(CRT_ERR_INVALID, w + ": null argument");
+    if (!s->committed) return fail(s->prepared ? CRT_ERR_NO_DEVICE : CRT_ERR_INVALID, w + ": scene not committed to a HIP device");
+    if (p->width == 0 || p->height == 0 || p->spp == 0) return fail(CRT_ERR_INVALID, w + ": empty frame or zero samples");
+    if (p->tile_ranks == 0 || p->tile_rank >= p->tile_ranks) return fail(CRT_ERR_INVALID, w + ": tile_rank must be < tile_ranks");
+    if ((uint64_t)p->width * p->height > (1ull << 31)) return fail(CRT_ERR_LIMIT, w + ": more than 2^31 pixels");
     if (p->width > 65535u || p->height > 65535u || p->spp > 65535u || p->max_depth > 255u)
-        return fail(CRT_ERR_LIMIT, "crt_render: width, height, spp must be <= 65535 and max_depth <= 255 (packed lane state)");
+        return fail(CRT_ERR_LIMIT, w + ": width, height, spp must be <= 65535 and max_depth <= 255 (packed lane state)");
     const uint32_t chunks = p->sample_chunks > 1 ? p->sample_chunks : 1u;
     if (chunks > 1 && ((chunks & (chunks - 1u)) != 0 || p->spp % chunks != 0 || chunks > 1024u))
-        return fail(CRT_ERR_INVALID, "crt_render: sample_chunks must be a power of two (<= 1024) that divides spp");
-    HIP_TRY(hipSetDevice(s->device));
-    hipStream_t stream = (hipStream_t)p->stream;
+        return fail(CRT_ERR_INVALID, w + ": sample_chunks must be a power of two (<= 1024) that divides spp");
+    if (chunks > 1) {
+        const uint64_t tiles = (uint64_t)((p->width + 7u) / 8u) * ((p->height + 7u) / 8u);
+        const uint64_t units = ((tiles + p->tile_ranks - 1) / p->tile_ranks) * 64u * chunks;
+        if (units >= (1ull << 31)) return fail(CRT_ERR_LIMIT, w + ": pixels x sample_chunks does not fit the work counter");
+        // a partial row-major render (tile_ranks > 1 without CRT_OUT_COMPACT) leaves other ranks' pixels untouched
+        if (p->tile_ranks > 1 && !(p->flags & CRT_OUT_COMPACT)) return fail(CRT_ERR_INVALID, w + ": sample_chunks with tile_ranks > 1 needs CRT_OUT_COMPACT");
+    }
+    *chunks_out = chunks;
+    return CRT_OK;
+}
+
+static size_t output_floats(const crt_render_params *p)
+{
+    return (p->flags & CRT_OUT_COMPACT) ? (size_t)crt_compact_floats(p->width, p->height, p->tile_ranks) : (size_t)p->width * p->height * 3;
+}
+
+// One frame's kernels on `stream` of the copy `d` (whose device is current): clears the counters and runs the render kernel
+// into d_rgb -- with sample chunks into the slabs, followed by the chunk-sum pass.  ev0 / ev1 (nullable) are recorded around
+// the render kernel.  Allocates nothing.
+static int enqueue_render(const crt_scene *s, const DeviceScene &d, const crt_camera *cam, const crt_render_params *p, uint32_t chunks, float *d_rgb,
+                          int *d_ids, unsigned long long *d_counters, float *d_slabs, hipEvent_t ev0, hipEvent_t ev1, hipStream_t stream)
+{
+    const Tuning &t = s->tuning;
+    const size_t rgb_floats = output_floats(p);
+    RenderArgs ra{};
+    ra.width = p->width; ra.height = p->height; ra.tiles_x = (p->width + 7u) / 8u; ra.tiles_y = (p->height + 7u) / 8u;
+    ra.spp = p->spp; ra.sample_offset = p->sample_offset; ra.max_depth = p->max_depth; ra.ids_sample = p->ids_sample;
+    ra.tile_rank = p->tile_rank; ra.tile_ranks = p->tile_ranks;
+    ra.flags = ((p->flags & CRT_OUT_ACCUM) ? (uint32_t)RA_ACCUM : 0u) | ((p->flags & CRT_OUT_COMPACT) ? (uint32_t)RA_COMPACT : 0u);
+    ra.key0 = (uint32_t)p->seed; ra.key1 = (uint32_t)(p->seed >> 32);
+    // the pool kernel has no sample chunks: chosen here with launch_render's own condition, and the threshold with it
+    const bool pool = t.kernel == 1 && chunks == 1;
+    ra.kernel = pool ? (uint32_t)RK_POOL : (uint32_t)RK_LANES;
+    ra.sched_threshold = (uint32_t)(pool ? t.pool_refill : t.sched_threshold);
+    ra.bvh_depth = s->bvh.depth;
+    ra.node_cache = (uint32_t)t.node_cache;
+    ra.blocks_per_stripe = t.stripe_bands ? 1u : 0u; // bands by default (+0.5 % cats, +2 % on the 1 M-triangle grid); launch_render sets the count
+    ra.chunks = chunks;
+    ra.chunk_stride = (uint32_t)(rgb_floats / 3);
+    float *d_target = d_rgb;
+    if (chunks > 1) { d_target = d_slabs; ra.flags |= (uint32_t)RA_ACCUM; } // raw chunk sums into one slab per chunk
+    HIP_TRY(hipMemsetAsync(d_counters, 0, CRT_COUNTER_BYTES, stream));
+    if (ev0) HIP_TRY(hipEventRecord(ev0, stream));
+    HIP_TRY(launch_render(d.view, *reinterpret_cast<const CameraPOD *>(cam), ra, d_target, d_ids, d_counters, (p->flags & CRT_COUNT_WORK) != 0,
+                          d.cus * (uint32_t)t.waves_per_cu, stream));
+    if (ev1) HIP_TRY(hipEventRecord(ev1, stream));
+    if (chunks > 1) HIP_TRY(launch_finalize_chunks(d_slabs, chunks, rgb_floats, p->spp, (p->flags & CRT_OUT_ACCUM) != 0, d_rgb, stream));
+    return CRT_OK;
+}
+
+// The scratch set of `stream` on `d`, with counters, events and (sample chunks) slabs of the size this frame needs.
+static int acquire_scratch(DeviceScene &d, hipStream_t stream, uint32_t chunks, size_t rgb_floats, StreamScratch **out)
+{
     hipEvent_t handover = nullptr;
-    crt_scene::StreamScratch *x = s->scratch_for(stream, &handover);
+    StreamScratch *x = d.scratch_for(stream, &handover);
     if (handover) HIP_TRY(hipStreamWaitEvent(stream, handover, 0)); // the set's previous owner finishes first
     if (!x->d_counters) {
         HIP_TRY(hipMalloc((void **)&x->d_counters, CRT_COUNTER_BYTES));
@@ -671,55 +815,7 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
         HIP_TRY(hipEventCreate(&x->ev1));
         HIP_TRY(hipEventCreate(&x->ev_done));
     }
-
-    RenderArgs ra{};
-    ra.width = p->width; ra.height = p->height; ra.tiles_x = (p->width + 7u) / 8u; ra.tiles_y = (p->height + 7u) / 8u;
-    ra.spp = p->spp; ra.sample_offset = p->sample_offset; ra.max_depth = p->max_depth; ra.ids_sample = p->ids_sample;
-    ra.tile_rank = p->tile_rank; ra.tile_ranks = p->tile_ranks;
-    ra.flags = ((p->flags & CRT_OUT_ACCUM) ? (uint32_t)RA_ACCUM : 0u) | ((p->flags & CRT_OUT_COMPACT) ? (uint32_t)RA_COMPACT : 0u);
-    ra.key0 = (uint32_t)p->seed; ra.key1 = (uint32_t)(p->seed >> 32);
-    ra.kernel = get_env_int("CRT_KERNEL", 0) == 1 ? (uint32_t)RK_POOL : (uint32_t)RK_LANES;
-    ra.sched_threshold = ra.kernel == RK_POOL ? (uint32_t)std::min(std::max(get_env_int("CRT_POOL_REFILL", 16), 1), 63)
-                                              : (uint32_t)std::min(std::max(get_env_int("CRT_SCHED_THRESHOLD", 44), 1), 64);
-    ra.bvh_depth = s->bvh.depth;
-    ra.node_cache = (uint32_t)std::min(std::max(get_env_int("CRT_NODE_CACHE", 1), 0), 2); // 0 off, 1 when the frame fills the GPU, 2 always; // trees up to 16 deep: LDS copy of the top of the tree (launch_render)
-    ra.blocks_per_stripe = get_env_int("CRT_STRIPE_BANDS", 1) ? 1u : 0u; // bands by default (+0.5 % cats, +2 % on the 1 M-triangle grid); launch_render sets the count
-
-    const size_t npix = (size_t)p->width * p->height;
-    const size_t rgb_floats = (p->flags & CRT_OUT_COMPACT) ? (size_t)crt_compact_floats(p->width, p->height, p->tile_ranks) : npix * 3;
-    const bool rgb_on_device = is_device_pointer(out_rgb);
-    const bool ids_on_device = out_ids ? is_device_pointer(out_ids) : true;
-    float *d_rgb = out_rgb;
-    int *d_ids = out_ids;
-    if (!rgb_on_device) {
-        if (s->stage_rgb_floats < rgb_floats) {
-            if (s->d_stage_rgb) (void)hipFree(s->d_stage_rgb);
-            s->d_stage_rgb = nullptr; s->stage_rgb_floats = 0;
-            HIP_TRY(hipMalloc((void **)&s->d_stage_rgb, rgb_floats * sizeof(float)));
-            s->stage_rgb_floats = rgb_floats;
-        }
-        d_rgb = s->d_stage_rgb;
-        // a partial (tile_ranks > 1, row-major) render leaves other ranks' pixels untouched: start from the caller's content
-        if (p->tile_ranks > 1 && !(p->flags & CRT_OUT_COMPACT)) HIP_TRY(hipMemcpyAsync(d_rgb, out_rgb, rgb_floats * sizeof(float), hipMemcpyHostToDevice, stream));
-    }
-    if (out_ids && !ids_on_device) {
-        if (s->stage_ids < npix) {
-            if (s->d_stage_ids) (void)hipFree(s->d_stage_ids);
-            s->d_stage_ids = nullptr; s->stage_ids = 0;
-            HIP_TRY(hipMalloc((void **)&s->d_stage_ids, npix * sizeof(int)));
-            s->stage_ids = npix;
-        }
-        d_ids = s->d_stage_ids;
-        if (p->tile_ranks > 1) HIP_TRY(hipMemcpyAsync(d_ids, out_ids, npix * sizeof(int), hipMemcpyHostToDevice, stream));
-    }
-
-    // sample chunks: the kernel writes raw chunk sums into one slab per chunk, then the slabs are added in chunk order
-    float *d_target = d_rgb;
-    ra.chunks = chunks;
-    ra.chunk_stride = (uint32_t)(rgb_floats / 3);
     if (chunks > 1) {
-        const uint64_t units = (uint64_t)((ra.tiles_x * ra.tiles_y + ra.tile_ranks - 1) / ra.tile_ranks) * 64u * chunks;
-        if (units >= (1ull << 31)) return fail(CRT_ERR_LIMIT, "crt_render: pixels x sample_chunks does not fit the work counter");
         const size_t need = rgb_floats * chunks;
         if (x->chunk_slab_floats < need) {
             if (x->d_chunk_slabs) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(x->d_chunk_slabs); }
@@ -727,41 +823,381 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
             HIP_TRY(hipMalloc((void **)&x->d_chunk_slabs, need * sizeof(float)));
             x->chunk_slab_floats = need;
         }
-        // a partial row-major render (tile_ranks > 1 without CRT_OUT_COMPACT) leaves other ranks' pixels untouched
-        if (p->tile_ranks > 1 && !(p->flags & CRT_OUT_COMPACT))
-            return fail(CRT_ERR_INVALID, "crt_render: sample_chunks with tile_ranks > 1 needs CRT_OUT_COMPACT");
-        d_target = x->d_chunk_slabs;
-        ra.flags |= (uint32_t)RA_ACCUM;
+    }
+    *out = x;
+    return CRT_OK;
+}
+
+// Synchronises `stream` and reads the counters of the frame last rendered with set `x`.
+static int read_counters(StreamScratch *x, hipStream_t stream, unsigned long long c[32], float *kernel_ms)
+{
+    HIP_TRY(hipMemcpyAsync(c, x->d_counters, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (c[CRT_COUNTER_GUARD]) return fail(CRT_ERR_HIP, "crt_render: a render wave left through its trip-counter guard (scheduling bug): the frame is incomplete");
+    HIP_TRY(hipEventElapsedTime(kernel_ms, x->ev0, x->ev1));
+    return CRT_OK;
+}
+
+static void add_stats(crt_stats *stats, const unsigned long long c[32], float kernel_ms)
+{
+    stats->rays += c[0]; stats->nodes += c[1]; stats->tri_tests += c[2]; stats->sphere_tests += c[3]; stats->tie_refolds += c[4]; stats->shaded_hits += c[5];
+    for (int k = 0; k < 10; k++) stats->sched[k] += c[8 + k];
+    stats->kernel_ms = std::max(stats->kernel_ms, kernel_ms);
+}
+
+static void print_sections(const unsigned long long c[32])
+{ // tuning aid: where the waves of the instrumented kernel spend their time
+    static const char *const name[9] = { "votes", "hit+shade", "store+fetch", "philox", "scatter", "camera", "spheres+root box", "node steps", "leaf steps" };
+    unsigned long long total = 0;
+    for (int k = 0; k < 9; k++) total += c[18 + k];
+    for (int k = 0; k < 9; k++) fprintf(stderr, "crt sections: %-17s %5.1f %%\n", name[k], total ? 100.0 * (double)c[18 + k] / (double)total : 0.0);
+}
+
+template <class T>
+static int grow(T **buf, size_t *have, size_t need)
+{
+    if (*have >= need) return CRT_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr; *have = 0;
+    HIP_TRY(hipMalloc((void **)buf, need * sizeof(T)));
+    *have = need;
+    return CRT_OK;
+}
+
+extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_render_params *p, float *out_rgb, int32_t *out_ids, crt_stats *stats)
+{
+    crt_scene *s = const_cast<crt_scene *>(cs);
+    uint32_t chunks = 1;
+    int rc = check_render_params(s, cam, p, out_rgb, "crt_render", &chunks);
+    if (rc) return rc;
+    DeviceScene &d = s->dev[0];
+    HIP_TRY(hipSetDevice(d.device));
+    hipStream_t stream = (hipStream_t)p->stream;
+    const size_t npix = (size_t)p->width * p->height;
+    const size_t rgb_floats = output_floats(p);
+    StreamScratch *x = nullptr;
+    std::unique_lock<std::mutex> lock(s->mutex); // held while the frame is enqueued, not while the host waits for it
+    if ((rc = acquire_scratch(d, stream, chunks, rgb_floats, &x))) return rc;
+
+    const bool stated = (p->flags & CRT_OUT_DEVICE) != 0;
+    const bool rgb_on_device = stated || is_device_pointer(out_rgb);
+    const bool ids_on_device = out_ids ? (stated || is_device_pointer(out_ids)) : true;
+    float *d_rgb = out_rgb;
+    int *d_ids = out_ids;
+    if (!rgb_on_device) { // staged through this stream's own buffer: host-pointer renders on different streams do not meet
+        if (x->stage_rgb_floats < rgb_floats) HIP_TRY(hipStreamSynchronize(stream));
+        if ((rc = grow(&x->d_stage_rgb, &x->stage_rgb_floats, rgb_floats))) return rc;
+        d_rgb = x->d_stage_rgb;
+        // a partial (tile_ranks > 1, row-major) render leaves other ranks' pixels untouched: start from the caller's content
+        if (p->tile_ranks > 1 && !(p->flags & CRT_OUT_COMPACT)) HIP_TRY(hipMemcpyAsync(d_rgb, out_rgb, rgb_floats * sizeof(float), hipMemcpyHostToDevice, stream));
+    }
+    if (out_ids && !ids_on_device) {
+        if (x->stage_ids < npix) HIP_TRY(hipStreamSynchronize(stream));
+        if ((rc = grow(&x->d_stage_ids, &x->stage_ids, npix))) return rc;
+        d_ids = x->d_stage_ids;
+        if (p->tile_ranks > 1) HIP_TRY(hipMemcpyAsync(d_ids, out_ids, npix * sizeof(int), hipMemcpyHostToDevice, stream));
     }
 
-    HIP_TRY(hipMemsetAsync(x->d_counters, 0, CRT_COUNTER_BYTES, stream));
-    HIP_TRY(hipEventRecord(x->ev0, stream));
-    HIP_TRY(launch_render(s->view, *reinterpret_cast<const CameraPOD *>(cam), ra, d_target, d_ids, x->d_counters, (p->flags & CRT_COUNT_WORK) != 0, s->max_waves, stream));
-    HIP_TRY(hipEventRecord(x->ev1, stream));
-    if (chunks > 1) HIP_TRY(launch_finalize_chunks(x->d_chunk_slabs, chunks, rgb_floats, p->spp, (p->flags & CRT_OUT_ACCUM) != 0, d_rgb, stream));
+    if ((rc = enqueue_render(s, d, cam, p, chunks, d_rgb, d_ids, x->d_counters, x->d_chunk_slabs, x->ev0, x->ev1, stream))) return rc;
     HIP_TRY(hipEventRecord(x->ev_done, stream));
     x->recorded = true;
 
     if (!rgb_on_device) HIP_TRY(hipMemcpyAsync(out_rgb, d_rgb, rgb_floats * sizeof(float), hipMemcpyDeviceToHost, stream));
     if (out_ids && !ids_on_device) HIP_TRY(hipMemcpyAsync(out_ids, d_ids, npix * sizeof(int), hipMemcpyDeviceToHost, stream));
+    lock.unlock();
     if (stats) {
         unsigned long long c[32];
-        HIP_TRY(hipMemcpyAsync(c, x->d_counters, sizeof c, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-        memset(stats, 0, sizeof *stats);
-        stats->rays = c[0]; stats->nodes = c[1]; stats->tri_tests = c[2]; stats->sphere_tests = c[3]; stats->tie_refolds = c[4]; stats->shaded_hits = c[5];
-        for (int k = 0; k < 10; k++) stats->sched[k] = c[8 + k];
-        if ((p->flags & CRT_COUNT_WORK) && get_env_int("CRT_PRINT_SECTIONS", 0)) { // tuning aid: where the waves of the instrumented kernel spend their time
-            static const char *const name[9] = { "votes", "hit+shade", "store+fetch", "philox", "scatter", "camera", "spheres+root box", "node steps", "leaf steps" };
-            unsigned long long total = 0;
-            for (int k = 0; k < 9; k++) total += c[18 + k];
-            for (int k = 0; k < 9; k++) fprintf(stderr, "crt sections: %-17s %5.1f %%\n", name[k], total ? 100.0 * (double)c[18 + k] / (double)total : 0.0);
-        }
         float ms = 0.0f;
-        HIP_TRY(hipEventElapsedTime(&ms, x->ev0, x->ev1));
-        stats->kernel_ms = ms;
+        if ((rc = read_counters(x, stream, c, &ms))) return rc;
+        memset(stats, 0, sizeof *stats);
+        add_stats(stats, c, ms);
+        if ((p->flags & CRT_COUNT_WORK) && s->tuning.print_sections) print_sections(c);
     } else if (!rgb_on_device || (out_ids && !ids_on_device)) {
         HIP_TRY(hipStreamSynchronize(stream)); // host buffers must be complete on return
+    }
+    return CRT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// multi-GPU: one process, n devices (crt_scene_commit_devices / crt_render_multi)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+// RCCL is loaded on first use (dlopen): a single-GPU user of this library never maps it, and a process that already has
+// an RCCL (torch's) keeps that one.  Only the entry points named here are used.
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool load()
+    {
+        if (handle) return true;
+        for (const char *name : { "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so" }) {
+            handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (handle) break;
+        }
+        if (!handle) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(handle, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(handle, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(handle, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(handle, "ncclGroupEnd");
+        AllGather = (decltype(AllGather))dlsym(handle, "ncclAllGather");
+        Reduce = (decltype(Reduce))dlsym(handle, "ncclReduce");
+        GetErrorString = (decltype(GetErrorString))dlsym(handle, "ncclGetErrorString");
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && AllGather && Reduce && GetErrorString;
+    }
+};
+Rccl g_rccl;
+} // namespace
+
+#define RCCL_TRY(expr)                                                                                         \
+    do {                                                                                                       \
+        ncclResult_t r_ = (expr);                                                                              \
+        if (r_ != ncclSuccess) return fail(CRT_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+void crt_scene::release_multi()
+{
+    MultiState &m = multi;
+    for (size_t r = 0; r < m.rank.size(); r++) {
+        MultiRank &k = m.rank[r];
+        if (r < dev.size() && dev[r].device >= 0) (void)hipSetDevice(dev[r].device);
+        for (int i = 0; i < 2; i++) {
+            if (k.stream[i]) { (void)hipStreamSynchronize(k.stream[i]); }
+        }
+        if (k.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy((ncclComm_t)k.comm);
+        for (int i = 0; i < 2; i++) {
+            if (k.stream[i]) (void)hipStreamDestroy(k.stream[i]);
+            if (k.d_local[i]) (void)hipFree(k.d_local[i]);
+            if (k.d_all[i]) (void)hipFree(k.d_all[i]);
+            if (k.sent[i]) (void)hipEventDestroy(k.sent[i]);
+        }
+    }
+    if (!dev.empty() && dev[0].device >= 0) (void)hipSetDevice(dev[0].device);
+    if (m.d_stage_rgb) (void)hipFree(m.d_stage_rgb);
+    if (m.d_stage_ids) (void)hipFree(m.d_stage_ids);
+    for (int i = 0; i < 2; i++) if (m.frame_done[i]) (void)hipEventDestroy(m.frame_done[i]);
+    if (m.fork) (void)hipEventDestroy(m.fork);
+    m = MultiState();
+}
+
+extern "C" int crt_scene_commit_devices(crt_scene *s, const int *devices, uint32_t n, uint32_t flags)
+{
+    if (!s || !devices) return fail(CRT_ERR_INVALID, "crt_scene_commit_devices: null argument");
+    if (n == 0 || n > 64) return fail(CRT_ERR_INVALID, "crt_scene_commit_devices: 1 to 64 devices");
+    int rc = prepare_host(s, devices[0], flags);
+    if (rc) return rc;
+    s->dev.resize(n);
+    for (uint32_t k = 0; k < n; k++)
+        if ((rc = upload_replica(s, s->dev[k], devices[k]))) { s->release_device(); return rc; }
+    s->device = devices[0];
+    s->committed = true;
+
+    MultiState &m = s->multi;
+    m.rank.resize(n);
+    bool distinct = true;
+    for (uint32_t a = 0; a < n; a++) for (uint32_t b = a + 1; b < n; b++) if (devices[a] == devices[b]) distinct = false;
+    const char *tr = getenv("CRT_MULTI_TRANSPORT");
+    m.use_rccl = distinct && n > 1;
+    if (tr && !strcmp(tr, "copy")) m.use_rccl = false;
+    if (tr && !strcmp(tr, "rccl")) {
+        if (!distinct) { s->release_device(); return fail(CRT_ERR_INVALID, "crt_scene_commit_devices: CRT_MULTI_TRANSPORT=rccl needs distinct devices (a communicator refuses duplicates)"); }
+        m.use_rccl = true;
+    }
+    auto bail = [&](int code) { s->release_device(); return code; };
+    m.peer_ids = true;
+    for (uint32_t r = 0; r < n; r++) {
+        if (hipSetDevice(devices[r]) != hipSuccess) return bail(hip_fail(hipGetLastError(), "hipSetDevice"));
+        for (int i = 0; i < 2; i++) {
+            hipError_t e = hipStreamCreateWithFlags(&m.rank[r].stream[i], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&m.rank[r].sent[i], hipEventDisableTiming);
+            if (e != hipSuccess) return bail(hip_fail(e, "crt_scene_commit_devices: stream / event creation"));
+        }
+        if (devices[r] != devices[0]) { // so that rank r can write its primary-hit ids straight into the root's buffer
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, devices[r], devices[0]) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+            if (can) {
+                const hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+                (void)hipGetLastError();
+            }
+            if (!can) m.peer_ids = false;
+        }
+    }
+    if (hipSetDevice(devices[0]) != hipSuccess) return bail(hip_fail(hipGetLastError(), "hipSetDevice"));
+    for (int i = 0; i < 2; i++) {
+        const hipError_t e = hipEventCreateWithFlags(&m.frame_done[i], hipEventDisableTiming);
+        if (e != hipSuccess) return bail(hip_fail(e, "hipEventCreateWithFlags"));
+    }
+    {
+        const hipError_t e = hipEventCreateWithFlags(&m.fork, hipEventDisableTiming);
+        if (e != hipSuccess) return bail(hip_fail(e, "hipEventCreateWithFlags"));
+    }
+    if (m.use_rccl) {
+        if (!g_rccl.load()) return bail(fail(CRT_ERR_HIP, "crt_scene_commit_devices: librccl.so.1 could not be loaded (set CRT_MULTI_TRANSPORT=copy for peer copies)"));
+        std::vector<ncclComm_t> comms(n);
+        const ncclResult_t r_ = g_rccl.CommInitAll(comms.data(), (int)n, devices);
+        if (r_ != ncclSuccess) return bail(fail(CRT_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r_)));
+        for (uint32_t r = 0; r < n; r++) m.rank[r].comm = comms[r];
+    }
+    m.ready = true;
+    return CRT_OK;
+}
+
+extern "C" int crt_render_multi(const crt_scene *cs, const crt_camera *cam, const crt_render_params *p, int mode, float *out_rgb, int32_t *out_ids,
+                                crt_stats *stats)
+{
+    crt_scene *s = const_cast<crt_scene *>(cs);
+    uint32_t chunks = 1;
+    int rc = check_render_params(s, cam, p, out_rgb, "crt_render_multi", &chunks);
+    if (rc) return rc;
+    MultiState &m = s->multi;
+    if (!m.ready) return fail(CRT_ERR_INVALID, "crt_render_multi: commit the scene with crt_scene_commit_devices first");
+    if (mode != CRT_MULTI_TILE && mode != CRT_MULTI_SAMPLE) return fail(CRT_ERR_INVALID, "crt_render_multi: unknown mode");
+    if (p->tile_rank != 0 || p->tile_ranks != 1 || (p->flags & (CRT_OUT_ACCUM | CRT_OUT_COMPACT)))
+        return fail(CRT_ERR_INVALID, "crt_render_multi: the library partitions the frame itself (tile_rank 0 of 1, no CRT_OUT_ACCUM / CRT_OUT_COMPACT)");
+    const uint32_t n = (uint32_t)s->dev.size();
+    if (mode == CRT_MULTI_SAMPLE && p->spp % n) return fail(CRT_ERR_INVALID, "crt_render_multi: spp must be a multiple of the number of ranks in sample mode");
+    if (out_ids && !m.peer_ids) return fail(CRT_ERR_INVALID, "crt_render_multi: out_ids needs peer access from every rank's device to devices[0]");
+    const int root = s->dev[0].device;
+    const size_t npix = (size_t)p->width * p->height, frame_floats = npix * 3;
+
+    // what every rank renders
+    std::vector<crt_render_params> q(n, *p);
+    for (uint32_t r = 0; r < n; r++) {
+        if (mode == CRT_MULTI_TILE) { q[r].tile_rank = r; q[r].tile_ranks = n; q[r].flags |= CRT_OUT_COMPACT; }
+        else {
+            q[r].spp = p->spp / n; q[r].sample_offset = p->sample_offset + r * (p->spp / n); q[r].flags |= CRT_OUT_ACCUM;
+            uint32_t c = chunks;
+            while (c > 1 && q[r].spp % c) c >>= 1; // the rank's share of the samples must still divide into the chunks
+            q[r].sample_chunks = c;
+        }
+    }
+    const uint32_t rank_chunks = q[0].sample_chunks > 1 ? q[0].sample_chunks : 1u;
+    const size_t part = output_floats(&q[0]);                                  // floats of one rank's part (the same for every rank)
+    const size_t all = (mode == CRT_MULTI_TILE || !m.use_rccl) ? part * n : part; // the root's assembly buffer (ncclReduce needs one part only)
+
+    // buffers (grow only; a resize first waits for everything in flight)
+    bool resize = false;
+    for (uint32_t r = 0; r < n; r++) {
+        if (m.rank[r].local_floats < part) resize = true;
+        const bool needs_all = r == 0 || (m.use_rccl && mode == CRT_MULTI_TILE); // all-gather: every rank receives
+        if (needs_all && m.rank[r].all_floats < all) resize = true;
+    }
+    if (resize) {
+        for (uint32_t r = 0; r < n; r++) {
+            HIP_TRY(hipSetDevice(s->dev[r].device));
+            for (int i = 0; i < 2; i++) HIP_TRY(hipStreamSynchronize(m.rank[r].stream[i]));
+        }
+        for (uint32_t r = 0; r < n; r++) {
+            HIP_TRY(hipSetDevice(s->dev[r].device));
+            MultiRank &k = m.rank[r];
+            if (k.local_floats < part) {
+                for (int i = 0; i < 2; i++) { size_t have = k.local_floats; if ((rc = grow(&k.d_local[i], &have, part))) return rc; }
+                k.local_floats = part;
+            }
+            const bool needs_all = r == 0 || (m.use_rccl && mode == CRT_MULTI_TILE);
+            if (needs_all && k.all_floats < all) {
+                for (int i = 0; i < 2; i++) { size_t have = k.all_floats; if ((rc = grow(&k.d_all[i], &have, all))) return rc; }
+                k.all_floats = all;
+            }
+        }
+    }
+
+    HIP_TRY(hipSetDevice(root));
+    hipStream_t user = (hipStream_t)p->stream;
+    const bool stated = (p->flags & CRT_OUT_DEVICE) != 0;
+    const bool rgb_on_device = stated || is_device_pointer(out_rgb);
+    const bool ids_on_device = out_ids ? (stated || is_device_pointer(out_ids)) : true;
+    float *d_rgb = out_rgb;
+    int *d_ids = out_ids;
+    if (!rgb_on_device) { if ((rc = grow(&m.d_stage_rgb, &m.stage_rgb_floats, frame_floats))) return rc; d_rgb = m.d_stage_rgb; }
+    if (out_ids && !ids_on_device) { if ((rc = grow(&m.d_stage_ids, &m.stage_ids, npix))) return rc; d_ids = m.d_stage_ids; }
+
+    const int set = (int)(m.frames & 1u);
+    m.frames++;
+    HIP_TRY(hipEventRecord(m.fork, user)); // the frame starts after what the caller has enqueued on its stream so far
+
+    // ---- every rank renders its part on its own stream ----
+    std::vector<StreamScratch *> x(n, nullptr);
+    for (uint32_t r = 0; r < n; r++) {
+        MultiRank &k = m.rank[r];
+        HIP_TRY(hipSetDevice(s->dev[r].device));
+        hipStream_t st = k.stream[set];
+        HIP_TRY(hipStreamWaitEvent(st, m.fork, 0));
+        // this set's previous frame (two frames ago): its parts on the root have been consumed once that frame was complete
+        if (m.done_recorded[set]) HIP_TRY(hipStreamWaitEvent(st, m.frame_done[set], 0));
+        if ((rc = acquire_scratch(s->dev[r], st, rank_chunks, part, &x[r]))) return rc;
+        q[r].stream = st;
+        if ((rc = enqueue_render(s, s->dev[r], cam, &q[r], rank_chunks, k.d_local[set], d_ids, x[r]->d_counters, x[r]->d_chunk_slabs, x[r]->ev0, x[r]->ev1, st)))
+            return rc;
+        HIP_TRY(hipEventRecord(x[r]->ev_done, st));
+        x[r]->recorded = true;
+    }
+
+    // ---- ONE exchange: the parts travel to the root ----
+    float *d_all = m.rank[0].d_all[set];
+    if (m.use_rccl) {
+        RCCL_TRY(g_rccl.GroupStart());
+        for (uint32_t r = 0; r < n; r++) {
+            MultiRank &k = m.rank[r];
+            ncclResult_t e;
+            if (mode == CRT_MULTI_TILE) e = g_rccl.AllGather(k.d_local[set], k.d_all[set], part, ncclFloat, (ncclComm_t)k.comm, k.stream[set]);
+            else e = g_rccl.Reduce(k.d_local[set], r == 0 ? (void *)d_all : (void *)k.d_local[set], part, ncclFloat, ncclSum, 0, (ncclComm_t)k.comm, k.stream[set]);
+            if (e != ncclSuccess) { (void)g_rccl.GroupEnd(); return fail(CRT_ERR_HIP, std::string("RCCL collective: ") + g_rccl.GetErrorString(e)); }
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+        HIP_TRY(hipSetDevice(root));
+    } else {
+        for (uint32_t r = 0; r < n; r++) {
+            MultiRank &k = m.rank[r];
+            HIP_TRY(hipSetDevice(s->dev[r].device));
+            HIP_TRY(hipMemcpyPeerAsync(d_all + (size_t)r * part, root, k.d_local[set], s->dev[r].device, part * sizeof(float), k.stream[set]));
+            if (r > 0) { HIP_TRY(hipEventRecord(k.sent[set], k.stream[set])); k.sent_recorded[set] = true; }
+        }
+        HIP_TRY(hipSetDevice(root));
+        for (uint32_t r = 1; r < n; r++) HIP_TRY(hipStreamWaitEvent(m.rank[0].stream[set], m.rank[r].sent[set], 0));
+    }
+
+    // ---- epilogue on the root, behind the previous frame's (frames complete in submission order) ----
+    hipStream_t rs = m.rank[0].stream[set];
+    if (m.done_recorded[set ^ 1]) HIP_TRY(hipStreamWaitEvent(rs, m.frame_done[set ^ 1], 0));
+    if (mode == CRT_MULTI_TILE) HIP_TRY(launch_untile(d_all, p->width, p->height, n, d_rgb, rs));
+    else if (m.use_rccl) HIP_TRY(launch_finalize(d_all, frame_floats, p->spp, d_rgb, rs));
+    else HIP_TRY(launch_finalize_chunks(d_all, n, frame_floats, p->spp, false, d_rgb, rs)); // the n sums added in rank order, /spp, gamma
+    if (out_ids && n > 1) { // other ranks wrote ids into the root's buffer from their own streams
+        for (uint32_t r = 1; r < n; r++) {
+            if (m.use_rccl) { // (copy transport: sent[r] already covers rank r's render)
+                HIP_TRY(hipSetDevice(s->dev[r].device));
+                HIP_TRY(hipEventRecord(m.rank[r].sent[set], m.rank[r].stream[set]));
+                HIP_TRY(hipSetDevice(root));
+                HIP_TRY(hipStreamWaitEvent(rs, m.rank[r].sent[set], 0));
+            }
+        }
+    }
+    HIP_TRY(hipEventRecord(m.frame_done[set], rs));
+    m.done_recorded[set] = true;
+    HIP_TRY(hipStreamWaitEvent(user, m.frame_done[set], 0));
+
+    if (!rgb_on_device) HIP_TRY(hipMemcpyAsync(out_rgb, d_rgb, frame_floats * sizeof(float), hipMemcpyDeviceToHost, user));
+    if (out_ids && !ids_on_device) HIP_TRY(hipMemcpyAsync(out_ids, d_ids, npix * sizeof(int), hipMemcpyDeviceToHost, user));
+    if (stats) {
+        memset(stats, 0, sizeof *stats);
+        for (uint32_t r = 0; r < n; r++) {
+            HIP_TRY(hipSetDevice(s->dev[r].device));
+            unsigned long long c[32];
+            float ms = 0.0f;
+            if ((rc = read_counters(x[r], m.rank[r].stream[set], c, &ms))) return rc;
+            add_stats(stats, c, ms);
+        }
+        HIP_TRY(hipSetDevice(root));
+        HIP_TRY(hipStreamSynchronize(user));
+    } else if (!rgb_on_device || (out_ids && !ids_on_device)) {
+        HIP_TRY(hipStreamSynchronize(user));
     }
     return CRT_OK;
 }

@@ -31,8 +31,13 @@ struct RenderArgs {
 };
 
 // counters: 32 x uint64 on the device: [0] rays [1] nodes [2] triangle tests [3] sphere tests [4] tie refolds [5] shaded hits [6] pixel work counter
-// (pool kernel) [8..17] wave-level schedule counters (crt_stats.sched) [18..26] section clocks (CRT_PRINT_SECTIONS) [28] block counters used up
+// (pool kernel) [7] guard trips [8..17] wave-level schedule counters (crt_stats.sched) [18..26] section clocks (CRT_PRINT_SECTIONS) [28] block counters used up
 #define CRT_COUNTER_USED_UP 28
+// [7]: waves that left a render kernel through its trip-counter guard (must be 0; crt_render reports CRT_ERR_HIP otherwise)
+#define CRT_COUNTER_GUARD 7
+// passes of render_kernel's main loop a wave may make (a pass is a shade phase or a run of walk steps, 0.3 us at the very
+// least: 2^28 passes are minutes, three orders of magnitude above the longest frame in BASELINE.json)
+#define CRT_GUARD_PASSES (1u << 28)
 // bytes of the counter buffer: 32 x uint64 (the above, padded) + 64 block counters of the work queue, 256 B apart
 #define CRT_COUNTER_BYTES (32 * 8 + 64 * 256)
 hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,

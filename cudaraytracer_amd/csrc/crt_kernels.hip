@@ -1,9 +1,13 @@
 // crt_kernels.hip -- gfx950 kernels of the hot path and their launchers.
 //
-// render_kernel: one wave64 = one 8x8 pixel tile (the reference's block shape, kernel.cu:50-51, renderer.h:51-52),
-// one lane = one pixel, all samples of the pixel summed in the lane in sample order (renderer.h:28-32), so the
-// float sum is the reference's sum whatever the tile-to-GPU assignment.  The traversal stack is an LDS column per
-// lane (stack[level][lane]: bank = lane, conflict free).
+// render_kernel: persistent wave64 waves.  A lane owns one work unit at a time -- a pixel, or one chunk of a pixel's
+// samples -- taken in blocks of CRT_FETCH_BLOCK units from 64 striped block counters (units are numbered in 8x8-tile
+// order: the reference's block shape, kernel.cu:50-51, renderer.h:51-52); a unit's samples are summed in the lane in
+// sample order (renderer.h:28-32), so the float sum is the reference's whatever the partition.  Waves run four to a
+// workgroup and share an LDS copy of the top of the tree (CRT_NODE_CACHE_NODES = 192 nodes for trees up to 16 deep: 4 x
+// 4.6 KB of stack + 12 KB of nodes = 30 KB, five workgroups = 20 waves per CU; 64 nodes for trees up to 24 deep), or one
+// to a workgroup without it.  The traversal stack is an LDS column per lane (stack[level][lane]: bank = lane, conflict
+// free).
 #include <hip/hip_runtime.h>
 
 #include "crt_kernels.h"
@@ -214,10 +218,10 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                                                                        int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
     // W waves per workgroup, each on its own; with NC > 0 they share an LDS copy of the first NC nodes (breadth-first
-    // numbering: the top of the tree).  The kernel is limited by L1 accesses as much as by VALU issue (one more dwordx4
-    // load per node step costs 13 % of the frame), and 77 % of the node visits of the headline scene go to the first 256
-    // nodes: those become ds_read_b128.  5 waves x 4.6 KB of stack + 16 KB of nodes = 39 KB: four workgroups per CU, the
-    // same 20 waves as with one wave per workgroup.
+    // numbering: the top of the tree).  The kernel is limited by the CU's address unit as much as by VALU issue (one more
+    // dwordx4 load per node step costs 13 % of the frame), and about 70 % of the node visits of the headline scene go to the
+    // first 192 nodes: those become ds_read_b128.  W = 4, NC = 192, SD = 16: 4 x 4.6 KB of stack + 12 KB of nodes = 30 KB,
+    // five workgroups per CU = the same 20 waves as with one wave per workgroup.
     __shared__ int lds_stack_all[W][(SD + 2) * 64]; // SD = 16 when the BVH is at most 16 levels deep
     __shared__ v4f lds_nodes[NC > 0 ? 4 * NC : 1];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -261,11 +265,16 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
     SectionClock<COUNT_WORK> clk; // [0] votes [1] hit + shade [2] store + fetch [3] Philox [4] scatter [5] camera [6] spheres + root box [7] node steps [8] leaf steps
     clk.start();
 
-    for (;;) {
+    // Every pass of this loop makes progress (a shade phase retires or starts a path segment for every ready lane, a walk
+    // phase advances at least one walk by a step), so it ends; the trip counter turns a scheduling bug into a flag the
+    // host reports (counters[CRT_COUNTER_GUARD], checked by crt_render) instead of a wave that never leaves the GPU.
+    bool guard_tripped = false;
+    for (uint32_t guard = 0;; guard++) {
         const bool walking = tv.cur != CRT_BVH_NONE;
         const int nwalk = popc64(__ballot(walking));
         const int nready = popc64(__ballot(!walking && phase != P_DONE));
         if (nready + nwalk == 0) break;
+        if (guard >= CRT_GUARD_PASSES) { guard_tripped = true; break; }
         if (nready >= threshold || nwalk == 0) {
             // ================================ phase A ================================
             if constexpr (COUNT_WORK) { if (lane == 0) { wc[0]++; wc[1] += nready; } }
@@ -497,6 +506,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
     if (lane == 0) {
         atomicAdd(&counters[0], (unsigned long long)rays_wave);
         if (refolds) atomicAdd(&counters[4], (unsigned long long)refolds);
+        if (guard_tripped) atomicAdd(&counters[CRT_COUNTER_GUARD], 1ull); // must stay 0
     }
     if constexpr (COUNT_WORK) {
         const uint32_t n = wave_sum(cnt.nodes), t = wave_sum(cnt.tris), sp = wave_sum(cnt.spheres), sh = wave_sum(cnt.shades);
@@ -850,7 +860,7 @@ __global__ __launch_bounds__(64 * W) void render_pool_kernel(SceneView sc, Camer
     if (lane == 0) {
         atomicAdd(&counters[0], (unsigned long long)rays);
         if (refolds) atomicAdd(&counters[4], (unsigned long long)refolds);
-        if (live != 0) atomicAdd(&counters[7], 1ull); // must stay 0: a wave left with unfinished contexts (guard tripped)
+        if (live != 0) atomicAdd(&counters[CRT_COUNTER_GUARD], 1ull); // must stay 0: a wave left with unfinished contexts (guard tripped)
     }
     if constexpr (COUNT_WORK) {
         const uint32_t n = wave_sum(cnt.nodes), t = wave_sum(cnt.tris), sp = wave_sum(cnt.spheres), sh = wave_sum(cnt.shades);

@@ -108,6 +108,7 @@ class TileFrame:
         # and the de-interleave all the same (a 1-rank group: how the RCCL path is exercised on a single-GPU box)
         self.collective = world > 1 or force_collective
         self.slots = _Slots(device, pipelined)
+        self._dev_flag = capi.OUT_DEVICE if self.slots.gpu else 0  # device buffers: the library need not query the pointers
         nbuf = self.slots.n
         self._frame = [torch.zeros(height * width * 3, dtype=torch.float32, device=device) for _ in range(nbuf)]
         self._local = [torch.zeros(self.n, dtype=torch.float32, device=device) for _ in range(nbuf)] if self.collective else None
@@ -132,9 +133,9 @@ class TileFrame:
         with self.slots.on(st):
             if not self.collective:
                 return scene.render(cam, self.width, self.height, spp, max_depth=max_depth, seed=seed, out_rgb=self._frame[slot].data_ptr(),
-                                    want_stats=want_stats, stream=self.slots.handle(st), flags=flags, sample_chunks=self.sample_chunks)[2]
+                                    want_stats=want_stats, stream=self.slots.handle(st), flags=flags | self._dev_flag, sample_chunks=self.sample_chunks)[2]
             return scene.render(cam, self.width, self.height, spp, max_depth=max_depth, seed=seed, tile_rank=self.rank, tile_ranks=self.world,
-                                flags=flags | capi.OUT_COMPACT, out_rgb=self._local[slot].data_ptr(), want_stats=want_stats,
+                                flags=flags | capi.OUT_COMPACT | self._dev_flag, out_rgb=self._local[slot].data_ptr(), want_stats=want_stats,
                                 stream=self.slots.handle(st), sample_chunks=self.sample_chunks)[2]
 
     def gather_async(self):
@@ -177,6 +178,7 @@ class SampleFrame:
         while self.sample_chunks > 1 and self.spp_local % self.sample_chunks:
             self.sample_chunks //= 2
         self.slots = _Slots(device, pipelined)
+        self._dev_flag = capi.OUT_DEVICE if self.slots.gpu else 0
         nbuf = self.slots.n
         self._accum = [torch.zeros(height * width * 3, dtype=torch.float32, device=device) for _ in range(nbuf)]
         self._frame = [torch.zeros(height * width * 3, dtype=torch.float32, device=device) for _ in range(nbuf if rank == 0 else 1)]
@@ -198,7 +200,7 @@ class SampleFrame:
         self._current = (slot, st)
         with self.slots.on(st):
             return scene.render(cam, self.width, self.height, self.spp_local, max_depth=max_depth, seed=seed, sample_offset=self.rank * self.spp_local,
-                                flags=flags | capi.OUT_ACCUM, out_rgb=self._accum[slot].data_ptr(), want_stats=want_stats,
+                                flags=flags | capi.OUT_ACCUM | self._dev_flag, out_rgb=self._accum[slot].data_ptr(), want_stats=want_stats,
                                 stream=self.slots.handle(st), sample_chunks=self.sample_chunks)[2]
 
     def reduce_async(self):

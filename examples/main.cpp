@@ -1,9 +1,12 @@
 // examples/main.cpp -- the reference's driver flow (kernel.cu:44-103: camera -> scene -> renderer -> render -> export ->
 // free) written against the drop-in headers.  Own code; build:
 //   g++ -O2 -std=c++17 examples/main.cpp -Lcudaraytracer_amd -lcrt_hip -Wl,-rpath,$PWD/cudaraytracer_amd -o crt_demo
-//   ./crt_demo [model.obj] [width] [height] [spp]
+//   ./crt_demo [model.obj] [width] [height] [spp] [--gpus N | --gpus d0,d1,...] [--mode tile|sample]
+// --gpus N shares the frame among HIP devices 0..N-1; a device list may name a device more than once (logical ranks on
+// one GPU).
 #include <chrono>
 #include <cmath>
+#include <cstring>
 #include <iostream>
 
 #include "../cudaraytracer_amd/cpp/renderer.h"
@@ -11,6 +14,21 @@
 
 int main(int argc, char **argv)
 {
+    std::vector<int> devices;
+    int multi_mode = CRT_MULTI_TILE;
+    { // options are taken out of argv; the positional arguments stay where the reference-style code below expects them
+        int kept = 1;
+        for (int k = 1; k < argc; k++) {
+            if (!strcmp(argv[k], "--gpus") && k + 1 < argc) {
+                const char *v = argv[++k];
+                if (strchr(v, ',')) { for (const char *q = v; *q;) { devices.push_back(atoi(q)); q = strchr(q, ','); if (!q) break; q++; } }
+                else for (int d = 0; d < atoi(v); d++) devices.push_back(d);
+            } else if (!strcmp(argv[k], "--mode") && k + 1 < argc) {
+                multi_mode = !strcmp(argv[++k], "sample") ? CRT_MULTI_SAMPLE : CRT_MULTI_TILE;
+            } else argv[kept++] = argv[k];
+        }
+        argc = kept;
+    }
     const float ASPECT_RATIO = 16.0f / 9.0f;
     const std::string model = argc > 1 ? argv[1] : "models/cat.obj";
     const uint32_t IMAGE_WIDTH = argc > 2 ? (uint32_t)atoi(argv[2]) : 1000, IMAGE_HEIGHT = argc > 3 ? (uint32_t)atoi(argv[3]) : 1000;
@@ -33,6 +51,7 @@ int main(int argc, char **argv)
     Hittable *world = nullptr;
     Hittable **d_world = &world;
     Scene scene;
+    scene.devices = devices;
     if (spheres) scene.launch_random_scene_kernel(d_world);
     else {
         scene.load_models({ model });
@@ -41,6 +60,8 @@ int main(int argc, char **argv)
     std::clog << "- Scene Created\n";
 
     Renderer renderer(IMAGE_WIDTH, IMAGE_HEIGHT, tx, ty, spp);
+    renderer.devices = devices; // empty: the reference's single-GPU path
+    renderer.multi_mode = multi_mode;
     const auto start = std::chrono::steady_clock::now();
     renderer.launch_kernel_render(framebuffer.data(), d_camera, d_world);
     const double timer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();

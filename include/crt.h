@@ -16,7 +16,7 @@
 extern "C" {
 #endif
 
-#define CRT_VERSION 100
+#define CRT_VERSION 200
 
 /* ---- error convention -------------------------------------------------------------------------------- */
 enum {
@@ -94,6 +94,18 @@ int crt_scene_commit(crt_scene *s, int device);
  * CRT_BUILD_GPU_LBVH when the environment has CRT_BUILDER=lbvh. */
 enum { CRT_BUILD_GPU_LBVH = 1u };
 int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags);
+/* Multi-GPU, one process driving n HIP devices (new: the reference is single-GPU, renderer.h:64-73 / kernel.cu:77-88;
+ * BASELINE.json asks for tile / sample partitioning over the 8 GPUs of a node).  Like crt_scene_commit_ex, then the scene
+ * is replicated: devices[k] holds the copy that logical rank k of crt_render_multi renders from; rank 0 (devices[0]) is
+ * the root where frames are assembled, and the device crt_render uses.  The same device may be listed more than once
+ * (logical ranks that share a GPU: how the multi-rank path is exercised on a one-GPU machine); ranks then exchange
+ * their parts by device-to-device copies, otherwise through RCCL (one communicator per rank, ncclCommInitAll;
+ * CRT_MULTI_TRANSPORT=copy forces the copies).  n <= 64. */
+int crt_scene_commit_devices(crt_scene *s, const int *devices, uint32_t n, uint32_t flags);
+/* The library reads its tuning knobs from the environment (CRT_KERNEL, CRT_SCHED_THRESHOLD, CRT_POOL_REFILL,
+ * CRT_NODE_CACHE, CRT_STRIPE_BANDS, CRT_WAVES_PER_CU, CRT_PRINT_SECTIONS) once, at commit, not per frame; this reads
+ * them again for a committed scene (tuning runs and tests that switch kernel variants between frames). */
+int crt_scene_reload_tuning(crt_scene *s);
 
 typedef struct crt_scene_info {
     uint32_t num_triangles, num_spheres, num_materials, num_textures;
@@ -128,7 +140,8 @@ int crt_camera_init(crt_camera *cam, uint32_t width, const float lookfrom[3], co
 enum {
     CRT_OUT_ACCUM = 1u,     /* out_rgb receives raw per-pixel sums (no /spp, no gamma): sample-split mode   */
     CRT_OUT_COMPACT = 2u,   /* out_rgb is this rank's tiles only, tile-major (see crt_untile): tile mode    */
-    CRT_COUNT_WORK = 4u     /* also count node fetches / primitive tests (instrumented kernel, slower)      */
+    CRT_COUNT_WORK = 4u,    /* also count node fetches / primitive tests (instrumented kernel, slower)      */
+    CRT_OUT_DEVICE = 8u     /* the caller states that out_rgb / out_ids are device pointers: no pointer query per frame */
 };
 #define CRT_TILE 8u         /* tiles are 8x8 pixels = one wave64 (reference block shape, kernel.cu:50-51)   */
 
@@ -168,12 +181,34 @@ typedef struct crt_stats {
  * `ids_sample` (-1 = miss).  Both may be device pointers (any HIP allocation on the scene's device) or host
  * pointers (staged through an internal device buffer).  With stats != NULL the call synchronises `stream`
  * before returning; with stats == NULL and device pointers it is asynchronous on `stream`.
- * Calls on one stream run in order.  Calls on different streams may overlap on the GPU: the scene keeps one set of
- * scratch buffers (work counters, chunk slabs) per stream, up to four sets; a fifth stream takes over the least recently
- * used set and waits for that set's last render.  The render kernel is persistent and fills the GPU, so what overlaps is
+ * Calls on one stream run in order.  Calls on different streams may overlap on the GPU, and may come from different host
+ * threads (one thread per stream; everything else about a handle stays single-threaded): the scene keeps one set of
+ * scratch buffers (work counters, chunk slabs, the staging of host-pointer frames) per stream, up to four sets; a fifth
+ * stream takes over the least recently used set and waits for that set's last render.  The render kernel is persistent and fills the GPU, so what overlaps is
  * the end of one frame with the start of the next (dist.py and bench.py keep two frames in flight this way). */
 int crt_render(const crt_scene *s, const crt_camera *cam, const crt_render_params *p, float *out_rgb, int32_t *out_ids,
                crt_stats *stats);
+
+/* The same frame rendered by all the devices of crt_scene_commit_devices (n logical ranks), assembled on devices[0].
+ *   CRT_MULTI_TILE   : 8x8 tile k goes to rank k % n (fine interleave: pixels over the mesh cost ~10x background pixels);
+ *                      every rank renders a compact tile list, ONE all-gather (ncclAllGather in a group over the n
+ *                      communicators, or n peer copies) and crt_untile's kernel on the root.  Bitwise equal to crt_render.
+ *   CRT_MULTI_SAMPLE : rank r renders samples [r*spp/n, (r+1)*spp/n) of every pixel into raw float sums, ONE reduce(sum)
+ *                      to the root (ncclReduce in a group; with peer copies the n sums are added in rank order, which is
+ *                      deterministic) and crt_finalize's kernel.  Equal to crt_render up to float summation order.
+ *                      spp must be a multiple of n.
+ * p->tile_rank / tile_ranks must be 0 / 1 and CRT_OUT_ACCUM / CRT_OUT_COMPACT must not be set (the library partitions);
+ * p->spp is the whole frame's sample count.  out_rgb: device pointer on devices[0], or host pointer.  out_ids
+ * (nullable, device pointer on devices[0] or host): every rank writes the ids of its own pixels / sample straight into
+ * the root's buffer, which needs peer access from its device to devices[0].
+ * Consecutive frames alternate between two sets of streams and buffers per rank, so a rank's next frame starts while the
+ * exchange of its previous one is still in flight.  With stats == NULL, device pointers and CRT_OUT_DEVICE the call is
+ * asynchronous: the frame is complete for work enqueued afterwards on p->stream (a stream of devices[0]; NULL = its
+ * default stream).  Otherwise the call returns when the frame is in out_rgb.  stats: sums over the ranks, kernel_ms =
+ * the slowest rank's kernel. */
+enum { CRT_MULTI_TILE = 0, CRT_MULTI_SAMPLE = 1 };
+int crt_render_multi(const crt_scene *s, const crt_camera *cam, const crt_render_params *p, int mode, float *out_rgb, int32_t *out_ids,
+                     crt_stats *stats);
 
 /* number of floats of a CRT_OUT_COMPACT buffer for one rank: ceil(ntiles / tile_ranks) * 64 * 3 (same for every rank) */
 uint64_t crt_compact_floats(uint32_t width, uint32_t height, uint32_t tile_ranks);

@@ -46,6 +46,8 @@ def hostsim():
 def capi():
     from cudaraytracer_amd import capi as c
     c.lib()  # raises loudly if libcrt_hip.so is not built
+    # the library reads its CRT_* tuning knobs at commit; tests switch kernel variants between renders of one scene
+    c.RELOAD_TUNING_EACH_RENDER = True
     return c
 
 

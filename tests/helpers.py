@@ -37,10 +37,10 @@ class HostSim:
                               tile_ranks=tile_ranks, flags=flags, ids_sample=ids_sample, sample_chunks=0, seed=seed, stream=None)
         out = np.zeros((height, width, 3), np.float32)
         ids = np.full((height, width), -2, np.int32)
-        st = (C.c_uint64 * 6)()
+        st = (C.c_uint64 * 8)()
         rc = self.L.hostsim_render(scene._h, C.byref(cam), C.byref(p), out.ctypes.data, ids.ctypes.data, st)
         assert rc == 0
-        return out, ids, dict(rays=st[0], nodes=st[1], tri_tests=st[2], sphere_tests=st[3], tie_refolds=st[4], max_stack=st[5])
+        return out, ids, dict(rays=st[0], nodes=st[1], tri_tests=st[2], sphere_tests=st[3], tie_refolds=st[4], max_stack=st[5], shaded_hits=st[6])
 
     def trace(self, scene, o, d, tmin=0.001, force_tie_path=False):
         t, took = C.c_float(), C.c_int()

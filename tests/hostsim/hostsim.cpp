@@ -32,13 +32,13 @@ struct ArrayStack {
 };
 struct HostCounters {
     static constexpr bool sphere_slots = true;
-    uint64_t nodes = 0, tris = 0, spheres = 0, rays = 0, refolds = 0;
+    uint64_t nodes = 0, tris = 0, spheres = 0, rays = 0, refolds = 0, shades = 0;
     void node() { nodes++; }
     void tri() { tris++; }
     void sphere() { spheres++; }
     void ray() { rays++; }
     void refold() { refolds++; }
-    void shade() {}
+    void shade() { shades++; }
 };
 SceneView host_view(const crt_scene *s, std::vector<Sphere> &spheres)
 {
@@ -52,7 +52,7 @@ SceneView host_view(const crt_scene *s, std::vector<Sphere> &spheres)
 } // namespace
 
 // Same contract as crt_render (row-major output, host pointers), executed lane by lane on the CPU.
-// stats_out[0..5] = rays, nodes, tri tests, sphere tests, tie refolds, deepest stack use.
+// stats_out[0..6] = rays, nodes, tri tests, sphere tests, tie refolds, deepest stack use, shaded hits.
 extern "C" int hostsim_render(const crt_scene *s, const crt_camera *cam, const crt_render_params *p, float *out_rgb, int32_t *out_ids,
                               uint64_t *stats_out)
 {
@@ -88,6 +88,7 @@ extern "C" int hostsim_render(const crt_scene *s, const crt_camera *cam, const c
     if (stats_out) {
         stats_out[0] = cnt.rays; stats_out[1] = cnt.nodes; stats_out[2] = cnt.tris; stats_out[3] = cnt.spheres; stats_out[4] = cnt.refolds;
         stats_out[5] = (uint64_t)stack.max_sp;
+        stats_out[6] = cnt.shades;
     }
     return CRT_OK;
 }

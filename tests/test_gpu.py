@@ -347,7 +347,10 @@ def test_pipelined_tile_gather_over_rccl_single_rank(scenes, gpu_scenes, capi):
     port = sock.getsockname()[1]
     sock.close()
     dev = torch.device("cuda", 0)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    kw = {}
+    if os.environ.get("CRT_TEST_PRIORITY_STREAM") == "1":   # the collectives on a high-priority stream (diagnostic runs)
+        kw["pg_options"] = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev, **kw)
     try:
         f = TileFrame(W, H, 1, 0, dev, sample_chunks=2, pipelined=True, force_collective=True)
         seeds, got = (3, 5, 7, 11, 13, 1984), []   # six frames over four buffer sets: two sets are used twice
@@ -468,3 +471,91 @@ def test_dielectric_and_checker_meshes(oracle, scenes, capi, node_cache):
     fb, rids, _, rst = oracle.RefScene(d).render(oracle.make_camera(params, width), width, height, spp, max_depth=12)
     assert np.array_equal(ids, rids) and st.rays == rst.rays
     assert np.array_equal(rgb, fb), "PSNR %.1f dB" % helpers.psnr(rgb, fb)
+
+
+def test_work_counters_equal_the_host_single_stepper(hostsim, scenes, gpu_scenes, capi, node_cache):
+    """The CRT_COUNT_WORK counters price the roofline (bench.py: lane_ops): nodes fetched, triangle / sphere tests, shaded
+    hits, path segments and tie refolds of a frame must equal the counts of the same per-lane code single-stepped on the
+    host (tests/hostsim), whatever the wave schedule and the kernel variant."""
+    desc, s = gpu_scenes("cats")
+    W, H, spp = 200, 113, 3
+    _, cam = scenes.make_camera(W)
+    hs = hostsim.build(desc)
+    want_rgb, want_ids, want = hostsim.render(hs, cam, W, H, spp)
+    for chunks in (0, 1):          # whole pixels; (3 samples: no power-of-two chunking beyond 1)
+        rgb, ids, st = s.render(cam, W, H, spp, want_ids=True, flags=capi.COUNT_WORK, sample_chunks=chunks)
+        got = dict(rays=st.rays, nodes=st.nodes, tri_tests=st.tri_tests, sphere_tests=st.sphere_tests, tie_refolds=st.tie_refolds, shaded_hits=st.shaded_hits)
+        assert got == {k: want[k] for k in got}, (got, want)
+        assert np.array_equal(rgb, want_rgb) and np.array_equal(ids, want_ids)
+    # chunked units walk the same rays: same counts
+    st4 = s.render(cam, W, H, 4, flags=capi.COUNT_WORK, sample_chunks=4)[2]
+    w4 = hostsim.render(hs, cam, W, H, 4)[2]
+    assert (st4.rays, st4.nodes, st4.tri_tests, st4.sphere_tests, st4.shaded_hits) == (w4["rays"], w4["nodes"], w4["tri_tests"], w4["sphere_tests"], w4["shaded_hits"])
+
+
+def test_benchmarked_configuration_at_full_size(scenes, gpu_scenes, capi):
+    """What bench.py times: cats, 1920x1080, 64 spp, sample_chunks = 32, frames alternating between two streams.  The raw
+    sums of the chunked frame must equal, bit for bit, the chunk-order float32 sum of 32 whole-pixel 2-spp renders at
+    sample_offset = 2c (each of those is the oracle-checked sequential path), and four frames issued back to back on two
+    alternating streams must all come out as that same frame."""
+    import torch
+    _, s = gpu_scenes("cats")
+    W, H, spp, n = 1920, 1080, 64, 32
+    _, cam = scenes.make_camera(W)
+    chunked = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
+    st = s.render(cam, W, H, spp, flags=capi.OUT_ACCUM | capi.OUT_DEVICE, out_rgb=chunked.data_ptr(), sample_chunks=n)[2]
+    total = torch.zeros_like(chunked)
+    part = torch.empty_like(chunked)
+    rays = 0
+    for c in range(n):
+        rays += s.render(cam, W, H, spp // n, sample_offset=c * (spp // n), flags=capi.OUT_ACCUM, out_rgb=part.data_ptr())[2].rays
+        total = part.clone() if c == 0 else total + part
+    torch.cuda.synchronize()
+    assert rays == st.rays and torch.equal(chunked, total)
+    # finished frame = those sums / spp, gamma (renderer.h:36-37, color.h:5-24)
+    frame = torch.empty_like(chunked)
+    s.render(cam, W, H, spp, out_rgb=frame.data_ptr(), sample_chunks=n)
+    v = total / spp
+    want = torch.where(v > 0, torch.sqrt(v), torch.zeros_like(v))
+    torch.cuda.synchronize()
+    assert torch.equal(frame, want)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.zeros_like(chunked) for _ in range(4)]
+    for k in range(4):
+        s.render(cam, W, H, spp, out_rgb=outs[k].data_ptr(), sample_chunks=n, want_stats=False, stream=streams[k % 2].cuda_stream,
+                 flags=capi.OUT_DEVICE)
+    for st_ in streams:
+        st_.synchronize()
+    for k in range(4):
+        assert torch.equal(outs[k], frame), k
+
+
+def test_host_pointer_renders_on_two_streams_from_two_threads(scenes, gpu_scenes):
+    """Host-pointer frames are staged through a device buffer; each stream has its own, so two threads rendering different
+    seeds on two streams never see each other's pixels."""
+    import threading
+    import torch
+    _, s0 = gpu_scenes("cats")
+    W, H, spp = 320, 180, 4
+    _, cam = scenes.make_camera(W)
+    seeds = {0: (11, 13, 17, 19), 1: (23, 29, 31, 37)}
+    want = {seed: s0.render(cam, W, H, spp, seed=seed, want_ids=True)[:2] for ss in seeds.values() for seed in ss}
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got, errors = {}, []
+
+    def worker(t):
+        try:
+            for seed in seeds[t]:
+                rgb, ids, _ = s0.render(cam, W, H, spp, seed=seed, want_ids=True, want_stats=(seed % 2 == 1), stream=streams[t].cuda_stream)
+                got[seed] = (rgb, ids)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    for seed, (rgb, ids) in want.items():
+        assert np.array_equal(got[seed][0], rgb) and np.array_equal(got[seed][1], ids), seed

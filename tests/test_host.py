@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol(capi):
     L = C.CDLL(capi.LIB_PATH)
     for name in declared:
         assert hasattr(L, name), name
-    assert capi.lib().crt_version() == 100
+    assert capi.lib().crt_version() == 200
 
 
 def test_struct_layouts_match_header(capi):

@@ -1,0 +1,139 @@
+"""Multi-GPU behind the C ABI (crt_scene_commit_devices / crt_render_multi): one process drives n devices.  On the one-GPU
+test box the n logical ranks all map to device 0 (the exchange is then peer copies, since an RCCL communicator refuses
+duplicate devices) plus a 1-device RCCL communicator, which sends the frame through ncclAllGather / ncclReduce for real."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+
+def test_tile_bookkeeping_on_the_host(capi):
+    """crt_compact_floats and the tile -> (rank, slot) dealing that crt_render_multi, crt_untile and dist.py share: every
+    pixel of a ragged frame is owned by exactly one rank, and the compact lists of all ranks have the same length."""
+    for (w, h, n) in [(1920, 1080, 8), (203, 117, 3), (8, 8, 5), (65, 9, 2), (3840, 2160, 8)]:
+        tiles = ((w + 7) // 8) * ((h + 7) // 8)
+        per = (tiles + n - 1) // n
+        assert capi.compact_floats(w, h, n) == per * 64 * 3
+        if w * h > 100000:
+            continue
+        m = helpers.tile_index_map(w, h, n)
+        owned = m[m >= 0]
+        assert owned.size == w * h and np.array_equal(np.sort(owned), np.arange(w * h))
+        frame = np.arange(w * h * 3, dtype=np.float32).reshape(h, w, 3)
+        parts = np.concatenate([helpers.to_compact(frame, r, n) for r in range(n)])
+        assert np.array_equal(helpers.untile_numpy(parts, w, h, n), frame)
+
+
+def test_multi_entry_points_fail_loudly_without_devices(capi, scenes):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    s = scenes.build(scenes.cat(), capi.DEVICE_NONE)
+    with pytest.raises(capi.CrtError) as e:
+        s.commit_devices([0, 0])
+    assert e.value.code in (capi.CRT_ERR_NO_DEVICE, capi.CRT_ERR_HIP)
+    _, cam = scenes.make_camera(64)
+    with pytest.raises(capi.CrtError):
+        s.render(cam, 64, 36, 1, multi=capi.MULTI_TILE)
+
+
+def _commit(scenes, capi, desc, devices):
+    s = capi.Scene()
+    for t in desc["textures"]:
+        s.add_texture(t["type"], t["a"], t.get("b"), t.get("scale", 1.0))
+    for m in desc["materials"]:
+        s.add_material(m["type"], m["rgb"], m["param"], capi.NO_TEXTURE if m["texture"] is None else m["texture"])
+    for me in desc["meshes"]:
+        s.add_mesh(me["vertices"], me["indices"], me["material"])
+    for sp in desc["spheres"]:
+        s.add_sphere(sp["center"], sp["radius"], sp["material"])
+    s.commit_devices(devices)
+    return s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [1, 2, 3, 8])
+def test_multi_tile_mode_is_bitwise_the_single_device_frame(oracle, capi, scenes, ranks):
+    desc = scenes.cats()
+    s = _commit(scenes, capi, desc, [0] * ranks)
+    W, H, spp = 203, 117, 4                                      # ragged
+    params, cam = scenes.make_camera(W)
+    single, ids1, st1 = s.render(cam, W, H, spp, want_ids=True)   # crt_render still works on a multi-device scene (devices[0])
+    rgb, ids, st = s.render(cam, W, H, spp, want_ids=True, multi=capi.MULTI_TILE)
+    assert np.array_equal(rgb, single) and np.array_equal(ids, ids1) and st.rays == st1.rays
+    fb, rids, _, rst = oracle.RefScene(desc).render(oracle.make_camera(params, W), W, H, spp)
+    assert np.array_equal(rgb, fb) and np.array_equal(ids, rids) and st.rays == rst.rays
+    # sample chunks + device pointers, asynchronous, several frames in flight over the two buffer sets
+    import torch
+    outs = [torch.zeros(H * W * 3, dtype=torch.float32, device="cuda") for _ in range(5)]
+    stream = torch.cuda.Stream()
+    seeds = (3, 5, 7, 11, 1984)
+    for seed, o in zip(seeds, outs):
+        s.render(cam, W, H, spp, seed=seed, out_rgb=o.data_ptr(), want_stats=False, stream=stream.cuda_stream, sample_chunks=2,
+                 flags=capi.OUT_DEVICE, multi=capi.MULTI_TILE)
+    stream.synchronize()
+    for seed, o in zip(seeds, outs):
+        want = s.render(cam, W, H, spp, seed=seed, sample_chunks=2)[0]
+        assert np.array_equal(o.cpu().numpy().reshape(want.shape), want), seed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [1, 2, 4])
+def test_multi_sample_mode_sums_rank_parts_in_rank_order(capi, scenes, ranks):
+    import torch
+    desc = scenes.cats()
+    s = _commit(scenes, capi, desc, [0] * ranks)
+    W, H, spp = 160, 90, 8
+    _, cam = scenes.make_camera(W)
+    single, ids1, st1 = s.render(cam, W, H, spp, want_ids=True, ids_sample=5)
+    rgb, ids, st = s.render(cam, W, H, spp, want_ids=True, ids_sample=5, multi=capi.MULTI_SAMPLE)
+    assert st.rays == st1.rays and np.array_equal(ids, ids1)
+    # the copy transport adds the ranks' raw sums in rank order: reproduce exactly from per-rank OUT_ACCUM renders
+    total = None
+    for r in range(ranks):
+        acc = s.render(cam, W, H, spp // ranks, sample_offset=r * (spp // ranks), flags=capi.OUT_ACCUM)[0]
+        total = acc.copy() if total is None else (total + acc).astype(np.float32)
+    v = (total / np.float32(spp)).astype(np.float32)
+    want = np.where(v > 0, np.sqrt(v, dtype=np.float32), np.float32(0)).astype(np.float32)
+    assert np.array_equal(rgb, want.reshape(rgb.shape))
+    assert np.allclose(rgb, single, rtol=3e-7, atol=1e-7)        # float association only
+
+
+@pytest.mark.gpu
+def test_multi_over_rccl_single_device_communicator(capi, scenes, monkeypatch):
+    """CRT_MULTI_TRANSPORT=rccl with one device: ncclCommInitAll, ncclAllGather / ncclReduce inside a group, then the
+    epilogue -- the code path eight distinct devices take, with a world of one."""
+    monkeypatch.setenv("CRT_MULTI_TRANSPORT", "rccl")
+    desc = scenes.cats()
+    s = _commit(scenes, capi, desc, [0])
+    W, H, spp = 203, 117, 4
+    _, cam = scenes.make_camera(W)
+    single, ids1, st1 = s.render(cam, W, H, spp, want_ids=True)
+    for mode in (capi.MULTI_TILE, capi.MULTI_SAMPLE):
+        for _ in range(3):                                       # both buffer sets, and one of them twice
+            rgb, ids, st = s.render(cam, W, H, spp, want_ids=True, multi=mode)
+            assert np.array_equal(rgb, single) and np.array_equal(ids, ids1) and st.rays == st1.rays
+    with pytest.raises(capi.CrtError):
+        _commit(scenes, capi, desc, [0, 0])                      # a communicator refuses duplicate devices: reported, not hung
+
+
+@pytest.mark.gpu
+def test_reference_style_driver_with_gpus_flag(oracle, scenes, tmp_path):
+    """examples/crt_demo --gpus N: Renderer::devices drives crt_scene_commit_devices / crt_render_multi.  One logical rank on
+    device 0 must give the single-device frame bit for bit; three logical ranks on device 0 as well (tile mode)."""
+    demo = os.path.join(helpers.REPO, "examples", "crt_demo")
+    W, H, spp = 200, 120, 3
+    params, _ = scenes.make_camera(W)
+    fb, _, _, _ = oracle.RefScene(scenes.cat()).render(oracle.make_camera(params, W), W, H, spp)
+    want = np.clip(fb * np.float32(255.0), 0, 255).astype(np.uint8)
+    header = ("P6\n%d %d\n255\n" % (W, H)).encode()
+    for gpus in ("1", "0,0,0"):
+        r = subprocess.run([demo, os.path.join(helpers.REPO, "models", "cat.obj"), str(W), str(H), str(spp), "--gpus", gpus], cwd=tmp_path,
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        raw = open(tmp_path / "output.ppm", "rb").read()
+        img = np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(H, W, 3)
+        assert np.array_equal(img, want), gpus

@@ -34,5 +34,14 @@ out["derived"] = {
     "l2_hit_rate": out["TCC_HIT_sum"] / (out["TCC_HIT_sum"] + out["TCC_MISS_sum"]),
     "valu_instructions_per_launch": out["SQ_INSTS_VALU"],
 }
+for name in ("bench.json", "bench_two_in_flight.json"):
+    if os.path.isfile(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, name))
+trace2 = os.path.join(src, "trace2", "trace2_kernel_trace.csv")
+if os.path.isfile(trace2) and os.path.isfile(os.path.join(src, "bench_two_in_flight.json")):
+    import subprocess
+    with open(os.path.join(dst, "two_in_flight_trace.json"), "w") as f:
+        subprocess.check_call([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "trace_overlap.py"), trace2,
+                               os.path.join(src, "bench_two_in_flight.json")], stdout=f)
 json.dump(out, open(os.path.join(dst, "pmc_render_kernel.json"), "w"), indent=1)
 print(json.dumps(out["derived"], indent=1))
