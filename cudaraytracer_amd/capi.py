@@ -18,6 +18,7 @@ MAT_LAMBERTIAN, MAT_METAL, MAT_DIFFUSE_LIGHT, MAT_DIELECTRIC = 0, 1, 2, 3
 BUILD_GPU_LBVH = 1
 OUT_ACCUM, OUT_COMPACT, COUNT_WORK, OUT_DEVICE = 1, 2, 4, 8
 MULTI_TILE, MULTI_SAMPLE = 0, 1
+NOALLOC_SLAB_BYTES = 32 << 20
 # tests set this: re-read the CRT_* tuning knobs before every render (the library reads them at commit only)
 RELOAD_TUNING_EACH_RENDER = False
 DEVICE_NONE = -1
@@ -63,7 +64,7 @@ class SceneInfo(C.Structure):  # crt_scene_info
 # every symbol include/crt.h declares (tests check that the library exports exactly these)
 SYMBOLS = ["crt_last_error", "crt_version", "crt_load_obj", "crt_load_obj_ex", "crt_free", "crt_scene_create", "crt_scene_destroy", "crt_scene_add_texture",
            "crt_scene_add_material", "crt_scene_add_mesh", "crt_scene_add_sphere", "crt_scene_commit", "crt_scene_commit_ex", "crt_scene_commit_devices", "crt_scene_reload_tuning", "crt_scene_get_info",
-           "crt_scene_get_ranks", "crt_camera_init", "crt_render", "crt_render_multi", "crt_compact_floats", "crt_untile", "crt_finalize", "crt_quantize_rgb8", "crt_write_png"]
+           "crt_scene_get_ranks", "crt_camera_init", "crt_render", "crt_render_noalloc", "crt_render_multi", "crt_compact_floats", "crt_untile", "crt_finalize", "crt_quantize_rgb8", "crt_write_png"]
 
 _lib = None
 
@@ -104,6 +105,7 @@ def bind(L):
     L.crt_scene_get_ranks.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.crt_camera_init.argtypes = [C.POINTER(Camera), C.c_uint32, f3, f3, f3, C.c_float, C.c_float, C.c_float, C.c_float]
     L.crt_render.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+    L.crt_render_noalloc.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_void_p, C.c_void_p, C.c_void_p]
     L.crt_render_multi.argtypes = [C.c_void_p, C.POINTER(Camera), C.POINTER(RenderParams), C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Stats)]
     L.crt_compact_floats.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     L.crt_compact_floats.restype = C.c_uint64
@@ -238,6 +240,16 @@ class Scene:
         if ids_np is not None:
             ids_np = ids_np.reshape(height, width)
         return rgb_np if rgb_np is not None else out_rgb, ids_np if ids_np is not None else out_ids, st
+
+
+def render_noalloc(scene, cam, width, height, spp, out_rgb, out_ids=None, out_rays=None, max_depth=10, seed=1984, sample_offset=0, ids_sample=0,
+                   tile_rank=0, tile_ranks=1, flags=0, stream=None, sample_chunks=0):
+    """crt_render_noalloc: device addresses only, asynchronous on `stream`, allocates nothing."""
+    p = RenderParams(width=width, height=height, spp=spp, sample_offset=sample_offset, max_depth=max_depth, tile_rank=tile_rank,
+                     tile_ranks=tile_ranks, flags=flags, ids_sample=ids_sample, sample_chunks=sample_chunks, seed=seed, stream=stream)
+    if RELOAD_TUNING_EACH_RENDER:
+        scene.reload_tuning()
+    _check(scene._L.crt_render_noalloc(scene._h, C.byref(cam), C.byref(p), out_rgb, out_ids, out_rays), scene._L)
 
 
 def untile(compact_all_ptr, width, height, tile_ranks, out_ptr, device=0, stream=None):

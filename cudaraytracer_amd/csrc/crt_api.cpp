@@ -622,6 +622,7 @@ static int upload_replica(crt_scene *s, DeviceScene &d, int device)
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     d.cus = (uint32_t)prop.multiProcessorCount;
+    HIP_TRY(noalloc_scratch_init(device)); // the device's copy of the static scratch of crt_render_noalloc (crt_kernels.hip)
     SceneView &v = d.view;
     v.nodes = (const q4 *)d.d_nodes; v.tris = (const q4 *)d.d_tris; v.spheres = (const Sphere *)d.d_spheres;
     v.shades = (const Shade *)d.d_shades; v.normals = (const q4 *)d.d_normals;
@@ -915,6 +916,32 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
     } else if (!rgb_on_device || (out_ids && !ids_on_device)) {
         HIP_TRY(hipStreamSynchronize(stream)); // host buffers must be complete on return
     }
+    return CRT_OK;
+}
+
+// crt_render for callers that cannot allocate (HIP graph capture, tight serving loops): the counters and the chunk slabs
+// live in the device's copy of a static __device__ array (crt_kernels.hip), whose address was taken when the scene was
+// committed to that device.  No hipMalloc / hipFree / event creation / host synchronisation here.
+extern "C" int crt_render_noalloc(const crt_scene *cs, const crt_camera *cam, const crt_render_params *p, float *out_rgb, int32_t *out_ids,
+                                  uint64_t *out_rays)
+{
+    crt_scene *s = const_cast<crt_scene *>(cs);
+    uint32_t chunks = 1;
+    int rc = check_render_params(s, cam, p, out_rgb, "crt_render_noalloc", &chunks);
+    if (rc) return rc;
+    const DeviceScene &d = s->dev[0];
+    unsigned char *scratch = (unsigned char *)noalloc_scratch_ptr(d.device);
+    if (!scratch) return fail(CRT_ERR_HIP, "crt_render_noalloc: the static scratch of this device was not set up at commit");
+    const size_t rgb_floats = output_floats(p);
+    if (chunks > 1 && (uint64_t)rgb_floats * chunks * sizeof(float) > (uint64_t)CRT_NOALLOC_SLAB_BYTES)
+        return fail(CRT_ERR_LIMIT, "crt_render_noalloc: output floats x sample_chunks x 4 exceeds the static scratch (CRT_NOALLOC_SLAB_BYTES = 32 MiB); "
+                                   "use fewer sample_chunks (1 needs no slab) or crt_render");
+    HIP_TRY(hipSetDevice(d.device));
+    hipStream_t stream = (hipStream_t)p->stream;
+    unsigned long long *d_counters = (unsigned long long *)scratch;
+    float *d_slabs = (float *)(scratch + CRT_NOALLOC_SLAB_OFFSET);
+    if ((rc = enqueue_render(s, d, cam, p, chunks, out_rgb, out_ids, d_counters, d_slabs, nullptr, nullptr, stream))) return rc;
+    if (out_rays) HIP_TRY(hipMemcpyAsync(out_rays, d_counters, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
     return CRT_OK;
 }
 

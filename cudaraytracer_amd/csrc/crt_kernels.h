@@ -40,6 +40,17 @@ struct RenderArgs {
 #define CRT_GUARD_PASSES (1u << 28)
 // bytes of the counter buffer: 32 x uint64 (the above, padded) + 64 block counters of the work queue, 256 B apart
 #define CRT_COUNTER_BYTES (32 * 8 + 64 * 256)
+// crt_render_noalloc's scratch: a static __device__ array in crt_kernels.hip, one copy per device that loads the code
+// object, holding the counter block and, behind it, the sample-chunk slabs of one frame.
+#define CRT_NOALLOC_SLAB_OFFSET 32768u                 // counters (CRT_COUNTER_BYTES = 16640) padded to a multiple of 256
+#ifndef CRT_NOALLOC_SLAB_BYTES
+#define CRT_NOALLOC_SLAB_BYTES (32u << 20)             // 32 MiB of chunk slabs: output floats x sample_chunks x 4 must fit (include/crt.h)
+#endif
+// Takes the address of `device`'s copy of the array (hipGetSymbolAddress; `device` must be the current device) and keeps
+// it; called once per device when a scene is committed to it.  noalloc_scratch_ptr returns the kept address (nullptr
+// before that).
+hipError_t noalloc_scratch_init(int device);
+void *noalloc_scratch_ptr(int device);
 hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,
                          bool count_work, uint32_t max_waves, hipStream_t stream);
 hipError_t launch_untile(const float *compact_all, uint32_t width, uint32_t height, uint32_t tile_ranks, float *out, hipStream_t stream);

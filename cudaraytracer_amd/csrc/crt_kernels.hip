@@ -10,6 +10,8 @@
 // free).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "crt_kernels.h"
 #include "crt_traverse.h"
 
@@ -923,6 +925,43 @@ __global__ __launch_bounds__(256) void finalize_chunks_kernel(const float *__res
         v = v > 0 ? __builtin_sqrtf(v) : 0.0f;
     }
     out[k] = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Static scratch of crt_render_noalloc (include/crt.h): counters + chunk slabs for callers that may not allocate.
+// `scratch` is a host-side stand-in for the symbol, not a device address: host code only ever uses the per-device
+// address hipGetSymbolAddress returned, taken once per device with that device current (each GPU holds its own copy of
+// the array at its own address) and handed to the kernels as an argument like any other buffer.
+// ---------------------------------------------------------------------------------------------------------
+static_assert(CRT_COUNTER_BYTES <= CRT_NOALLOC_SLAB_OFFSET && CRT_NOALLOC_SLAB_OFFSET % 256u == 0, "counter block must fit in front of the slabs");
+static __device__ __align__(256) unsigned char scratch[CRT_NOALLOC_SLAB_OFFSET + CRT_NOALLOC_SLAB_BYTES];
+namespace {
+constexpr int kMaxDevices = 64;
+void *g_scratch_ptr[kMaxDevices];
+std::mutex g_scratch_mutex;
+}
+
+hipError_t noalloc_scratch_init(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[device]) return hipSuccess;
+    int current = -1;
+    hipError_t e = hipGetDevice(&current);
+    if (e != hipSuccess) return e;
+    if (current != device) return hipErrorInvalidDevice; // the symbol's address is per device: the caller makes `device` current first
+    void *ptr = nullptr;
+    e = hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return e;
+    g_scratch_ptr[device] = ptr;
+    return hipSuccess;
+}
+
+void *noalloc_scratch_ptr(int device)
+{
+    if (device < 0 || device >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    return g_scratch_ptr[device];
 }
 
 hipError_t launch_finalize_chunks(const float *slabs, uint32_t chunks, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream)

@@ -189,6 +189,21 @@ typedef struct crt_stats {
 int crt_render(const crt_scene *s, const crt_camera *cam, const crt_render_params *p, float *out_rgb, int32_t *out_ids,
                crt_stats *stats);
 
+/* crt_render for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  (No counterpart in the reference, whose Renderer allocates and frees per frame, renderer.h:55-72.)
+ * Same frame, same kernels, same bits as crt_render, but the work counters and the sample-chunk slabs live in a static
+ * __device__ array of the library (16.6 KB of counters + CRT_NOALLOC_SLAB_BYTES = 32 MiB of slabs, one copy per GPU the
+ * library runs on, held until the process ends) whose per-device address is taken when a scene is committed to the
+ * device.  The call makes no hipMalloc / hipFree / event creation and never waits on the host: everything is enqueued on
+ * p->stream.  out_rgb and out_ids (nullable) must be device pointers; out_rays (nullable, device pointer) receives the
+ * frame's path-segment count.  Limits: with sample_chunks > 1, output floats x sample_chunks x 4 bytes must fit the
+ * 32 MiB of slabs (CRT_ERR_LIMIT otherwise; sample_chunks <= 1 needs no slab and has no size limit).  There is no
+ * crt_stats and no CRT_COUNT_WORK readout.  Every call on a GPU shares that GPU's array: the call clears what must start
+ * at zero, and two calls whose kernels overlap on one GPU (different streams) race -- keep them on one stream. */
+#define CRT_NOALLOC_SLAB_BYTES (32u << 20)
+int crt_render_noalloc(const crt_scene *s, const crt_camera *cam, const crt_render_params *p, float *out_rgb, int32_t *out_ids,
+                       uint64_t *out_rays);
+
 /* The same frame rendered by all the devices of crt_scene_commit_devices (n logical ranks), assembled on devices[0].
  *   CRT_MULTI_TILE   : 8x8 tile k goes to rank k % n (fine interleave: pixels over the mesh cost ~10x background pixels);
  *                      every rank renders a compact tile list, ONE all-gather (ncclAllGather in a group over the n

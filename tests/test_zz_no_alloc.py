@@ -1,0 +1,59 @@
+"""crt_render_noalloc (include/crt.h): the entry point for callers that cannot allocate.  Its output must be crt_render's,
+bit for bit, on two calls in a row, the second with a smaller input (the static scratch keeps the first call's contents)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(capi, s, cam, W, H, spp, chunks, **kw):
+    import torch
+    want = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
+    want_ids = torch.empty(H * W, dtype=torch.int32, device="cuda")
+    st = s.render(cam, W, H, spp, out_rgb=want.data_ptr(), out_ids=want_ids.data_ptr(), sample_chunks=chunks, flags=capi.OUT_DEVICE | kw.get("flags", 0),
+                  **{k: v for k, v in kw.items() if k != "flags"})[2]
+    got = torch.full_like(want, -1.0)
+    got_ids = torch.full_like(want_ids, -7)
+    rays = torch.zeros(1, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.Stream()
+    capi.render_noalloc(s, cam, W, H, spp, got.data_ptr(), got_ids.data_ptr(), rays.data_ptr(), sample_chunks=chunks, stream=stream.cuda_stream, **kw)
+    stream.synchronize()
+    assert torch.equal(got, want), "image differs from crt_render's: %d floats" % int((got != want).sum())
+    assert torch.equal(got_ids, want_ids) and int(rays.item()) == st.rays
+    return got
+
+
+def test_noalloc_matches_crt_render_twice_in_a_row(capi, scenes):
+    import torch
+    s = scenes.build(scenes.cats(), 0)
+    # first call: sample chunks (the slabs of the static scratch are used), 480 x 270 x 4 chunks = 6.2 MB of slabs
+    _, cam = scenes.make_camera(480)
+    _both(capi, s, cam, 480, 270, 8, 4)
+    # second call, smaller input, other seed and sample window, raw sums: nothing of the first frame may show through
+    _, cam2 = scenes.make_camera(203)
+    _both(capi, s, cam2, 203, 117, 4, 2, seed=7, sample_offset=11, ids_sample=12, flags=capi.OUT_ACCUM)
+    # whole pixels (no slab) at a size with a ragged tile edge, and a compact tile list of one rank of three
+    _both(capi, s, cam2, 203, 117, 3, 0)
+    n = capi.compact_floats(203, 117, 3)
+    want = torch.empty(n, dtype=torch.float32, device="cuda")
+    got = torch.full_like(want, -1.0)
+    s.render(cam2, 203, 117, 2, out_rgb=want.data_ptr(), tile_rank=1, tile_ranks=3, flags=capi.OUT_COMPACT | capi.OUT_DEVICE, sample_chunks=2)
+    capi.render_noalloc(s, cam2, 203, 117, 2, got.data_ptr(), tile_rank=1, tile_ranks=3, flags=capi.OUT_COMPACT, sample_chunks=2)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+
+
+def test_noalloc_rejects_what_does_not_fit(capi, scenes):
+    import torch
+    s = scenes.build(scenes.cat(), 0)
+    _, cam = scenes.make_camera(1920)
+    out = torch.empty(1080 * 1920 * 3, dtype=torch.float32, device="cuda")
+    # 1080p x 32 chunks = 796 MB of slabs: beyond the 32 MiB of the static scratch
+    with pytest.raises(capi.CrtError) as e:
+        capi.render_noalloc(s, cam, 1920, 1080, 64, out.data_ptr(), sample_chunks=32)
+    assert e.value.code == capi.CRT_ERR_LIMIT and "32 MiB" in str(e.value)
+    # the same frame with whole pixels needs no slab: accepted whatever the size
+    capi.render_noalloc(s, cam, 1920, 1080, 1, out.data_ptr())
+    torch.cuda.synchronize()
+    want = s.render(cam, 1920, 1080, 1)[0]
+    assert np.array_equal(out.cpu().numpy().reshape(want.shape), want)
