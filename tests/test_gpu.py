@@ -559,3 +559,46 @@ def test_host_pointer_renders_on_two_streams_from_two_threads(scenes, gpu_scenes
     assert not errors, errors
     for seed, (rgb, ids) in want.items():
         assert np.array_equal(got[seed][0], rgb) and np.array_equal(got[seed][1], ids), seed
+
+
+@pytest.mark.parametrize("workload", ["cats_4k", "cat_grid_4k"])
+def test_full_size_properties_3840x2160(scenes, gpu_scenes, capi, workload):
+    """BASELINE configs 4 and 5 at their own frame size (3840x2160: 518,400 tiles; with 32 sample chunks 2^24.9 work units
+    and 3.2 GB of chunk slabs per stream), too slow for the oracle, so size-independent properties: bitwise run-to-run
+    determinism, tile split over 8 ranks (compact lists + crt_untile) == single launch bitwise, sample-split ray counts add
+    up, and the chunked frame agrees with the whole-pixel (sequential-sum, oracle-checked path) frame to float association."""
+    import torch
+    if workload == "cats_4k":
+        _, s = gpu_scenes("cats")
+        spp, chunks, cam_over = 32, 32, {}
+    else:
+        _, s = gpu_scenes("cat_grid")
+        spp, chunks, cam_over = 16, 16, scenes.GRID_CAMERA
+    W, H = 3840, 2160
+    _, cam = scenes.make_camera(W, **cam_over)
+    dev = capi.OUT_DEVICE
+    a = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
+    b = torch.zeros_like(a)
+    st_a = s.render(cam, W, H, spp, out_rgb=a.data_ptr(), sample_chunks=chunks, flags=dev)[2]
+    st_b = s.render(cam, W, H, spp, out_rgb=b.data_ptr(), sample_chunks=chunks, flags=dev)[2]
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and st_a.rays == st_b.rays
+    ranks = 8
+    n = capi.compact_floats(W, H, ranks)
+    allc = torch.zeros(ranks * n, dtype=torch.float32, device="cuda")
+    rays = 0
+    for r in range(ranks):
+        rays += s.render(cam, W, H, spp, tile_rank=r, tile_ranks=ranks, flags=capi.OUT_COMPACT | dev, out_rgb=allc[r * n:].data_ptr(), sample_chunks=chunks)[2].rays
+    capi.untile(allc.data_ptr(), W, H, ranks, b.data_ptr())
+    torch.cuda.synchronize()
+    assert rays == st_a.rays and torch.equal(a, b)
+    del allc
+    half = spp // 2
+    r0 = s.render(cam, W, H, half, sample_offset=0, flags=capi.OUT_ACCUM | dev, out_rgb=b.data_ptr(), sample_chunks=chunks // 2)[2].rays
+    r1 = s.render(cam, W, H, half, sample_offset=half, flags=capi.OUT_ACCUM | dev, out_rgb=b.data_ptr(), sample_chunks=chunks // 2)[2].rays
+    assert r0 + r1 == st_a.rays
+    st_w = s.render(cam, W, H, spp, out_rgb=b.data_ptr(), flags=dev)[2]          # whole pixels: the reference's sequential sums
+    torch.cuda.synchronize()
+    assert st_w.rays == st_a.rays and torch.allclose(a, b, rtol=3e-7, atol=1e-7)
+    img = a.cpu().numpy().reshape(H, W, 3)
+    assert np.isfinite(img).all() and img.min() >= 0 and img.mean() > 0.01
