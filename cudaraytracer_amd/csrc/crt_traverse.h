@@ -288,8 +288,47 @@ CRT_HD void walk(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int aft
     }
 }
 
+// The fold in reference leaf order over the candidates with t <= t_min + window: one MODE_NEXT_RANK walk per candidate,
+// the reference's own comparisons.  Only what happens after m -- the first candidate in rank order that attains t_min --
+// decides the result (m is accepted whenever it is visited and resets closest to t_min).  From there closest can creep up
+// by at most 1e-7 per accepted triangle (triangle.h:75), so a chain of candidates spaced ~1e-7 apart can carry it to the
+// end of the window and beyond; `reach` is the largest t the reference could still have accepted after m, and when it lies
+// outside the window the fold is done again over a window that contains it.  (Nearly always one pass; a second one needs
+// >= 9 successively accepted candidates behind the minimum.)
+template <class Stack, class Counters>
+CRT_HD int refold(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float t_min, float &t_hit, int &mat_hit, Stack &stack, Counters &cnt)
+{
+    float t_hi = t_min + CRT_TIE_WINDOW;
+    float closest = tmax;
+    int win = -1;
+    for (int pass = 0; pass < 64; pass++) {
+        closest = tmax;
+        win = -1;
+        int after = -1;
+        bool seen_min = false;
+        float reach = -FLT_MAX;
+        for (;;) {
+            Search n;
+            n.t = 0.0f; n.code = -1; n.mat = 0; n.rank = 0x7FFFFFFF; n.near_tie = false;
+            walk<MODE_NEXT_RANK>(sc, o, d, tmin, n, after, t_hi, stack, cnt);
+            if (n.code < 0) break;
+            const bool is_tri = (uint32_t)n.code < sc.ntris;
+            seen_min = seen_min || n.t == t_min;
+            if (is_tri ? triangle_accepts(n.t, closest) : sphere_accepts(n.t, closest)) {
+                closest = n.t; win = n.code; mat_hit = n.mat;
+                if (seen_min) reach = __builtin_fmaxf(reach, closest + 1e-7f); // what a later triangle may still reach (spheres need t <= closest)
+            }
+            after = n.rank;
+        }
+        if (!(reach > t_hi)) break;
+        t_hi = reach + CRT_TIE_WINDOW;
+    }
+    t_hit = closest;
+    return win;
+}
+
 // After a MODE_CLOSEST walk: the reference's winner.  Fast path when no two candidates came within the tie
-// window; otherwise the fold in reference leaf order (one MODE_NEXT_RANK walk per candidate in the window).
+// window; otherwise the fold in reference leaf order.
 template <class Stack, class Counters>
 CRT_HD int resolve_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, const Search &s, float &t_hit, int &mat_hit, Stack &stack, Counters &cnt)
 {
@@ -297,20 +336,7 @@ CRT_HD int resolve_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, 
     // sphere.h:36 / triangle.h:75 also bound t by the caller's tmax (FLT_MAX everywhere in the reference)
     if (!s.near_tie) { t_hit = s.t; mat_hit = s.mat; return s.t <= tmax ? s.code : -1; }
     cnt.refold();
-    const float t_hi = s.t + CRT_TIE_WINDOW;
-    float closest = tmax;
-    int win = -1, after = -1;
-    for (;;) {
-        Search n;
-        n.t = 0.0f; n.code = -1; n.mat = 0; n.rank = 0x7FFFFFFF; n.near_tie = false;
-        walk<MODE_NEXT_RANK>(sc, o, d, tmin, n, after, t_hi, stack, cnt);
-        if (n.code < 0) break;
-        const bool is_tri = (uint32_t)n.code < sc.ntris;
-        if (is_tri ? triangle_accepts(n.t, closest) : sphere_accepts(n.t, closest)) { closest = n.t; win = n.code; mat_hit = n.mat; }
-        after = n.rank;
-    }
-    t_hit = closest;
-    return win;
+    return refold(sc, o, d, tmin, tmax, s.t, t_hit, mat_hit, stack, cnt);
 }
 
 // world->hit(ray, Interval(tmin, FLT_MAX), rec) (camera.h:68 -> hittable_list.h:17-63): returns the winning

@@ -1,7 +1,7 @@
 // examples/main.cpp -- the reference's driver flow (kernel.cu:44-103: camera -> scene -> renderer -> render -> export ->
 // free) written against the drop-in headers.  Own code; build:
 //   g++ -O2 -std=c++17 examples/main.cpp -Lcudaraytracer_amd -lcrt_hip -Wl,-rpath,$PWD/cudaraytracer_amd -o crt_demo
-//   ./crt_demo [model.obj] [width] [height] [spp] [--gpus N | --gpus d0,d1,...] [--mode tile|sample]
+//   ./crt_demo [model.obj] [width] [height] [spp] [--gpus N | --gpus d0,d1,...] [--mode tile|sample] [--mtl]
 // --gpus N shares the frame among HIP devices 0..N-1; a device list may name a device more than once (logical ranks on
 // one GPU).
 #include <chrono>
@@ -16,6 +16,7 @@ int main(int argc, char **argv)
 {
     std::vector<int> devices;
     int multi_mode = CRT_MULTI_TILE;
+    bool from_mtl = false; // --mtl: every part of the model gets its .mtl material (Scene::materials_from_mtl, row N4) instead of the reference's one Lambertian
     { // options are taken out of argv; the positional arguments stay where the reference-style code below expects them
         int kept = 1;
         for (int k = 1; k < argc; k++) {
@@ -25,6 +26,8 @@ int main(int argc, char **argv)
                 else for (int d = 0; d < atoi(v); d++) devices.push_back(d);
             } else if (!strcmp(argv[k], "--mode") && k + 1 < argc) {
                 multi_mode = !strcmp(argv[++k], "sample") ? CRT_MULTI_SAMPLE : CRT_MULTI_TILE;
+            } else if (!strcmp(argv[k], "--mtl")) {
+                from_mtl = true;
             } else argv[kept++] = argv[k];
         }
         argc = kept;
@@ -52,6 +55,7 @@ int main(int argc, char **argv)
     Hittable **d_world = &world;
     Scene scene;
     scene.devices = devices;
+    scene.materials_from_mtl = from_mtl;
     if (spheres) scene.launch_random_scene_kernel(d_world);
     else {
         scene.load_models({ model });

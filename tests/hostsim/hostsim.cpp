@@ -115,18 +115,7 @@ extern "C" int hostsim_trace(const crt_scene *s, const float o_[3], const float 
         code = -1;
         if (q.code >= 0) {
             cnt.refold();
-            const float t_hi = q.t + CRT_TIE_WINDOW;
-            float closest = FLT_MAX;
-            int after = -1;
-            for (;;) {
-                Search n; n.t = 0.0f; n.code = -1; n.mat = 0; n.rank = 0x7FFFFFFF; n.near_tie = false;
-                walk<MODE_NEXT_RANK>(sc, o, d, tmin, n, after, t_hi, stack, cnt);
-                if (n.code < 0) break;
-                const bool is_tri = (uint32_t)n.code < sc.ntris;
-                if (is_tri ? triangle_accepts(n.t, closest) : sphere_accepts(n.t, closest)) { closest = n.t; code = n.code; }
-                after = n.rank;
-            }
-            t = closest;
+            code = refold(sc, o, d, tmin, FLT_MAX, q.t, t, mat, stack, cnt);
         }
     }
     if (took_tie_path) *took_tie_path = cnt.refolds > 0;

@@ -602,3 +602,69 @@ def test_full_size_properties_3840x2160(scenes, gpu_scenes, capi, workload):
     assert st_w.rays == st_a.rays and torch.allclose(a, b, rtol=3e-7, atol=1e-7)
     img = a.cpu().numpy().reshape(H, W, 3)
     assert np.isfinite(img).all() and img.min() >= 0 and img.mean() > 0.01
+
+
+_TWO_PART_OBJ = """# two objects, two materials, one of them emissive (row N4: crt_load_obj_ex + .mtl records)
+mtllib parts.mtl
+o body
+v -1.5 0.0 -1.0
+v 1.5 0.0 -1.0
+v 0.0 2.4 -0.2
+v 0.0 0.0 1.6
+vn 0 0 1
+usemtl clay
+f 1//1 2//1 3//1
+f 1//1 3//1 4//1
+f 2//1 4//1 3//1
+o lamp
+v -1.0 3.2 -1.0
+v 1.0 3.2 -1.0
+v 1.0 3.2 1.0
+v -1.0 3.2 1.0
+usemtl glow
+f 5//1 6//1 7//1 8//1
+"""
+_TWO_PART_MTL = """newmtl clay
+Kd 0.8 0.25 0.1
+Ns 10
+newmtl glow
+Kd 0.1 0.1 0.1
+Ke 12.0 11.0 9.0
+illum 2
+"""
+
+
+def test_obj_groups_and_mtl_materials_render_like_the_oracle(oracle, scenes, capi, tmp_path, node_cache):
+    """Row N4: a two-object, two-usemtl OBJ whose .mtl has an emissive record, through crt_load_obj_ex, mapped to materials
+    as Scene::materials_from_mtl does (DiffuseLight(Ke) where Ke > 0, else Lambertian(Kd)), rendered on the GPU and by the
+    oracle fed the same groups.  The quad is fan-triangulated; indices refer to the one joined vertex array."""
+    (tmp_path / "parts.obj").write_text(_TWO_PART_OBJ)
+    (tmp_path / "parts.mtl").write_text(_TWO_PART_MTL)
+    v, idx, tri_group, groups = capi.load_obj_groups(str(tmp_path / "parts.obj"))
+    assert [(g["object"], g["material"], g["num_triangles"]) for g in groups] == [("body", "clay", 3), ("lamp", "glow", 2)]
+    assert np.allclose(groups[1]["Ke"], (12.0, 11.0, 9.0)) and np.allclose(groups[0]["Kd"], (0.8, 0.25, 0.1)) and idx.shape == (5, 3)
+    assert np.array_equal(tri_group, [0, 0, 0, 1, 1])
+    d = scenes._base()
+    d["materials"].append(dict(type=capi.MAT_LAMBERTIAN, rgb=(0.7, 0.3, 0.16), param=0.0, texture=None))   # scene.h:147-148 (unused here, as in Scene)
+    for g in groups:
+        emits = any(c > 0 for c in g["Ke"])
+        d["materials"].append(dict(type=capi.MAT_DIFFUSE_LIGHT if emits else capi.MAT_LAMBERTIAN, rgb=tuple(g["Ke"] if emits else g["Kd"]), param=0.0, texture=None))
+        d["meshes"].append(dict(vertices=v[:, :3].copy(), indices=idx[g["first_triangle"]: g["first_triangle"] + g["num_triangles"]],
+                                material=len(d["materials"]) - 1))
+    scenes._add_ref_spheres(d)
+    s = scenes.build(d, 0)
+    W, H, spp = 160, 90, 4
+    params, cam = scenes.make_camera(W)
+    rgb, ids, st = s.render(cam, W, H, spp, want_ids=True)
+    fb, rids, _, rst = oracle.RefScene(d).render(oracle.make_camera(params, W), W, H, spp)
+    assert np.array_equal(ids, rids) and np.array_equal(rgb, fb) and st.rays == rst.rays
+    assert set(np.unique(ids)) >= {0, 3}            # the clay body and the lamp are both seen directly
+    # and the same file through the C++ surface (Scene::materials_from_mtl = true): examples/crt_demo --mtl
+    import subprocess
+    demo = os.path.join(helpers.REPO, "examples", "crt_demo")
+    r = subprocess.run([demo, str(tmp_path / "parts.obj"), str(W), str(H), str(spp), "--mtl"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    raw = open(tmp_path / "output.ppm", "rb").read()
+    header = ("P6\n%d %d\n255\n" % (W, H)).encode()
+    img = np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(H, W, 3)
+    assert np.array_equal(img, np.clip(fb * np.float32(255.0), 0, 255).astype(np.uint8))

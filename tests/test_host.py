@@ -252,3 +252,39 @@ def test_obj_groups_and_mtl_records(capi, tmp_path):
     assert idx.shape == (2196, 3) and len(groups) == 1 and groups[0]["material"] == "lambert1" and np.allclose(groups[0]["Kd"], 0.8)
     v0, i0 = capi.load_obj(os.path.join(helpers.REPO, "models", "cats.obj"))
     assert np.array_equal(i0, idx)
+
+
+def _creeping_chain_scene(capi, n=16, step=8.9e-8):
+    """n parallel triangles stacked `step` apart along +z, seen from z < 0.  The reference's leaf order is the Morton order of
+    the centroids, ascending in z among otherwise equal cells (ties: insertion order), i.e. nearest first: every triangle is
+    within 1e-7 of the one before it and
+    is accepted in turn (triangle.h:75), closest_so_far creeps from the nearest to the farthest, (n - 1) x 1e-7 behind the
+    minimum -- beyond the 1e-6 window the tie fold starts with.  (8.9e-8 = 2.99 ulp of t ~ 0.25: consecutive t differ by at
+    most 3 ulp, which fl(closest + 1e-7f) always covers.)"""
+    base = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32)
+    verts, idx = [], []
+    for k in range(n):
+        verts.append(base + np.array([0, 0, np.float32(k * step)], np.float32))       # the rays come from z = -0.25 along +z
+        idx.append([3 * k, 3 * k + 1, 3 * k + 2])
+    mats = [dict(type=capi.MAT_LAMBERTIAN, rgb=(0.2, 0.5, 0.8), param=0.0, texture=None)]
+    return dict(textures=[], materials=mats, meshes=[dict(vertices=np.concatenate(verts), indices=np.array(idx, np.uint32), material=0)], spheres=[])
+
+
+def test_tie_window_follows_a_creeping_chain(hostsim, oracle, capi):
+    """closest_so_far can creep past the fold's window through a chain of candidates ~1e-7 apart.  The fold notices
+    (the last accepted t + 1e-7 reaches beyond the window) and folds again over a wider window: the winner is the
+    reference's (the oracle walks its own LBVH without any window)."""
+    desc = _creeping_chain_scene(capi)
+    s = hostsim.build(desc)
+    rs = oracle.RefScene(desc)
+    assert np.array_equal(s.ranks(), rs.ranks())
+    rng = np.random.default_rng(11)
+    far_wins = 0
+    for _ in range(200):
+        o = np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.5, 0.2), -0.25], np.float32)     # t ~ 0.25: ulp 3e-8, so 1e-7 steps resolve
+        d = np.array([rng.uniform(-0.02, 0.02), rng.uniform(-0.02, 0.02), 1.0], np.float32)
+        ref_prim, ref_t = rs.trace(o, d)
+        prim, t, took = hostsim.trace(s, o, d)
+        assert prim == ref_prim and t == ref_t and took, (o, d, prim, ref_prim)
+        far_wins += ref_prim >= 13                                                             # > 1.1e-6 behind the nearest triangle
+    assert far_wins > 50
