@@ -27,10 +27,32 @@ struct LdsStack {
     __device__ __forceinline__ void push(int v) { *top = v; top += 64; }
     __device__ __forceinline__ int pop() { top -= 64; return *top; }
     // branch-free forms for the node step: the store always happens (one spare level above the deepest push takes it)
-    __device__ __forceinline__ int peek() const { return *(top - 64); }
+    __device__ __forceinline__ int peek() { return *(top - 64); }
     __device__ __forceinline__ void push_if(int v, bool c) { *top = v; top += c ? 64 : 0; }
     __device__ __forceinline__ void pop_if(bool c) { top -= c ? 64 : 0; }
 };
+
+// The same stack with its top entry in a lane register (BASELINE.json's "short stack in VGPRs spilling to LDS", one entry
+// deep): peek() costs nothing, but the branch-free node step must still read what a pop would uncover (now the second
+// entry) and store what a push covers (now the old top), so the LDS traffic per step is the same one read and one write,
+// and two more selects keep the register current.  Measured with -DCRT_REG_TOS=1: slower; kept for
+// the record, not used.
+struct RegTopStack {
+    int *top;  // next free LDS slot of this lane's column: entries [base, top) lie below `tos`
+    int *base;
+    int tos;   // the top entry
+    int spec;  // what a pop would uncover, read ahead by peek()
+    __device__ __forceinline__ void init(int *column) { column[0] = CRT_BVH_NONE; base = column + 64; top = base; tos = CRT_BVH_NONE; spec = CRT_BVH_NONE; }
+    __device__ __forceinline__ void reset() { top = base; tos = CRT_BVH_NONE; }
+    __device__ __forceinline__ void push(int v) { *top = tos; top += 64; tos = v; }
+    __device__ __forceinline__ int pop() { const int r = tos; top -= 64; tos = *top; return r; }
+    __device__ __forceinline__ int peek() { spec = *(top - 64); return tos; }
+    __device__ __forceinline__ void push_if(int v, bool c) { *top = tos; top += c ? 64 : 0; tos = c ? v : tos; }
+    __device__ __forceinline__ void pop_if(bool c) { top -= c ? 64 : 0; tos = c ? spec : tos; }
+};
+#ifndef CRT_REG_TOS
+#define CRT_REG_TOS 0
+#endif
 
 template <bool SS>
 struct RegCounters {
@@ -241,7 +263,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
     const uint32_t NO_PIXEL = 0xFFFFFFFFu;
     const float tmin = 0.001f; // camera.h:68
 
-    LdsStack stack;
+    typename std::conditional<CRT_REG_TOS != 0, RegTopStack, LdsStack>::type stack;
     stack.init(lds_stack + lane);
     typename std::conditional<COUNT_WORK, RegCounters<SS>, RayCounters<SS>>::type cnt;
     cnt.refold_counter = counters + 4;
