@@ -249,7 +249,7 @@ struct Tuning {
         kernel = get_env_int("CRT_KERNEL", 0) == 1 ? 1 : 0;
         pool_refill = std::min(std::max(get_env_int("CRT_POOL_REFILL", 16), 1), 63);
         sched_threshold = std::min(std::max(get_env_int("CRT_SCHED_THRESHOLD", 44), 1), 64);
-        node_cache = std::min(std::max(get_env_int("CRT_NODE_CACHE", 1), 0), 2);
+        node_cache = std::min(std::max(get_env_int("CRT_NODE_CACHE", 1), 0), 3);
         stripe_bands = get_env_int("CRT_STRIPE_BANDS", 1) ? 1 : 0;
         waves_per_cu = std::min(std::max(get_env_int("CRT_WAVES_PER_CU", 20), 1), 64);
         print_sections = get_env_int("CRT_PRINT_SECTIONS", 0);

@@ -232,10 +232,14 @@ static_assert(CRT_WORK_STRIPES == 64u, "the order in which a wave visits the blo
 #ifndef CRT_WAVES_PER_EU
 #define CRT_WAVES_PER_EU 5 // 512 VGPRs / 5 waves -> 96 registers per lane; the few spills this forces sit on the rare tie path
 #endif
+// (a 16-wave workgroup is the whole-tree-in-LDS variant: one workgroup per CU = 4 waves per SIMD = 128 registers per lane)
 #if CRT_WAVES_PER_EU > 0
-#define CRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(CRT_WAVES_PER_EU, CRT_WAVES_PER_EU)))
+#define CRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(W == 16 ? 4 : CRT_WAVES_PER_EU, W == 16 ? 4 : CRT_WAVES_PER_EU)))
 #else
 #define CRT_OCCUPANCY_ATTR
+#endif
+#ifndef CRT_WHOLE_TREE_NODES
+#define CRT_WHOLE_TREE_NODES 1344 // 16 x 4.6 KB of stack + 84 KB of nodes = 156 KB: one workgroup per CU
 #endif
 template <bool COUNT_WORK, int SD, bool SS, int W, int NC>
 __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
@@ -993,6 +997,22 @@ hipError_t launch_finalize_chunks(const float *slabs, uint32_t chunks, size_t n,
     return hipGetLastError();
 }
 
+// node_cache = 3: one 16-wave workgroup per CU holding the WHOLE node array in LDS (trees of at most CRT_WHOLE_TREE_NODES
+// nodes and 16 levels): no node is ever fetched from device memory.  Only instantiated for the 16-level stack (24 / 32
+// levels would not fit 160 KB).
+template <bool CW, int SD, bool SS>
+static bool launch_whole_tree(const SceneView &sc, const CameraPOD &cam, const RenderArgs &a, float *out, int *ids, unsigned long long *counters,
+                              uint32_t blocks, hipStream_t stream)
+{
+    if constexpr (SD == 16) {
+        if (a.node_cache == 3 && sc.nnodes <= CRT_WHOLE_TREE_NODES) {
+            hipLaunchKernelGGL((render_kernel<CW, 16, SS, 16, CRT_WHOLE_TREE_NODES>), dim3((blocks + 15u) / 16u), dim3(1024), 0, stream, sc, cam, a, out, ids, counters);
+            return true;
+        }
+    }
+    return false;
+}
+
 hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,
                          bool count_work, uint32_t max_waves, hipStream_t stream)
 {
@@ -1029,7 +1049,8 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     const bool ss = sc.sphere_slots != 0;
     if (a.node_cache == 1 && units < max_waves) a.node_cache = 0; // a frame that does not fill the GPU: single waves spread over more CUs than groups of four (2 = always)
     const int levels = ra.bvh_depth <= 16 ? 16 : ra.bvh_depth <= 24 ? 24 : CRT_STACK_DEPTH;
-#define CRT_LAUNCH(CW, SD, SS) do { if (a.node_cache && SD == 16) hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, CRT_NODE_CACHE_NODES>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters); \
+#define CRT_LAUNCH(CW, SD, SS) do { if (launch_whole_tree<CW, SD, SS>(sc, cam, a, out, ids, counters, blocks, stream)) {} \
+                                     else if (a.node_cache && SD == 16) hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, CRT_NODE_CACHE_NODES>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters); \
                                      else if (a.node_cache && SD == 24) hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, 64>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters); \
                                      else hipLaunchKernelGGL((render_kernel<CW, SD, SS, 1, 0>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters); } while (0)
 #define CRT_LAUNCH_SS(CW, SD) do { if (ss) CRT_LAUNCH(CW, SD, true); else CRT_LAUNCH(CW, SD, false); } while (0)

@@ -57,10 +57,11 @@ def scenes(capi):
     return s
 
 
-@pytest.fixture(params=["0", "2"], ids=["one-wave-groups", "lds-node-copy"])
+@pytest.fixture(params=["0", "2", "3"], ids=["one-wave-groups", "lds-node-copy", "whole-tree-in-lds"])
 def node_cache(request, monkeypatch):
     """Runs a GPU test with both kernel variants: one wave per workgroup (CRT_NODE_CACHE=0) and four waves sharing an LDS copy
     of the top of the tree (CRT_NODE_CACHE=2: always; the default, 1, picks it only for frames that fill the GPU, which
-    test-sized frames do not)."""
+    test-sized frames do not), and one 16-wave workgroup per CU holding the whole node array in LDS (CRT_NODE_CACHE=3: small trees
+    only; larger ones fall back to the four-wave variant)."""
     monkeypatch.setenv("CRT_NODE_CACHE", request.param)
     return request.param
