@@ -1147,7 +1147,7 @@ extern "C" int crt_render_multi(const crt_scene *cs, const crt_camera *cam, cons
 
     const int set = (int)(m.frames & 1u);
     m.frames++;
-    HIP_TRY(hipEventRecord(m.fork, user)); // the frame starts after what the caller has enqueued on its stream so far
+    HIP_TRY(hipEventRecord(m.fork, user)); // what the caller has enqueued on its stream so far
 
     // ---- every rank renders its part on its own stream ----
     std::vector<StreamScratch *> x(n, nullptr);
@@ -1155,7 +1155,10 @@ extern "C" int crt_render_multi(const crt_scene *cs, const crt_camera *cam, cons
         MultiRank &k = m.rank[r];
         HIP_TRY(hipSetDevice(s->dev[r].device));
         hipStream_t st = k.stream[set];
-        HIP_TRY(hipStreamWaitEvent(st, m.fork, 0));
+        // The renders read only the scene and write only the library's own buffers, so they do not wait for the caller's stream
+        // (it carries the previous frame's completion: waiting for it would serialise the frames); the epilogue, which writes
+        // out_rgb, does.  Ids go straight into the caller's buffer: then the renders wait as well.
+        if (out_ids) HIP_TRY(hipStreamWaitEvent(st, m.fork, 0));
         // this set's previous frame (two frames ago): its parts on the root have been consumed once that frame was complete
         if (m.done_recorded[set]) HIP_TRY(hipStreamWaitEvent(st, m.frame_done[set], 0));
         if ((rc = acquire_scratch(s->dev[r], st, rank_chunks, part, &x[r]))) return rc;
@@ -1192,6 +1195,7 @@ extern "C" int crt_render_multi(const crt_scene *cs, const crt_camera *cam, cons
 
     // ---- epilogue on the root, behind the previous frame's (frames complete in submission order) ----
     hipStream_t rs = m.rank[0].stream[set];
+    HIP_TRY(hipStreamWaitEvent(rs, m.fork, 0)); // what the caller enqueued before this call (the last reader of out_rgb) comes first
     if (m.done_recorded[set ^ 1]) HIP_TRY(hipStreamWaitEvent(rs, m.frame_done[set ^ 1], 0));
     if (mode == CRT_MULTI_TILE) HIP_TRY(launch_untile(d_all, p->width, p->height, n, d_rgb, rs));
     else if (m.use_rccl) HIP_TRY(launch_finalize(d_all, frame_floats, p->spp, d_rgb, rs));
