@@ -123,3 +123,134 @@ extern "C" int hostsim_trace(const crt_scene *s, const float o_[3], const float 
     if (t_out) *t_out = t;
     return surface_at(sc, code, o, d, t).prim;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Walk traces for the schedule simulator (tools/sched_sim.cpp): the per-lane event sequence of every path segment of a
+// subsample of the frame's 8x8 tiles, written as a byte stream:
+//   0xFD pixel start, 0xFE sample (path) start, 0xFF path segment start, 0x01 one inner-node step, 0x10 + k one leaf step with
+//   k primitive tests.  (Flat-sphere tests and shading are the same for every segment and are not recorded.)
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+std::vector<unsigned char> *g_trace = nullptr;
+int g_leaf_tests = 0;
+struct TraceCounters {
+    static constexpr bool sphere_slots = true;
+    void node() { g_trace->push_back(0x01); }
+    void tri() { g_leaf_tests++; }
+    void sphere() {}
+    void ray() { g_trace->push_back(0xFF); }
+    void refold() {}
+    void shade() {}
+};
+struct TraceStack : ArrayStack {
+    int pop() { g_trace->push_back((unsigned char)(0x10 + (g_leaf_tests > 15 ? 15 : g_leaf_tests))); g_leaf_tests = 0; return ArrayStack::pop(); } // the end of every leaf step
+};
+} // namespace
+
+extern "C" int hostsim_trace_file(const crt_scene *s, const crt_camera *cam, const crt_render_params *p, uint32_t tile_step, const char *path)
+{
+    if (!s || !s->prepared || !cam || !p || !path || tile_step == 0) return CRT_ERR_INVALID;
+    std::vector<Sphere> spheres;
+    const SceneView sc = host_view(s, spheres);
+    const CameraPOD &c = *reinterpret_cast<const CameraPOD *>(cam);
+    std::vector<unsigned char> trace;
+    g_trace = &trace;
+    TraceCounters cnt;
+    TraceStack stack;
+    const uint32_t tiles_x = (p->width + 7u) / 8u, tiles_y = (p->height + 7u) / 8u;
+    for (uint32_t tile = 0; tile < tiles_x * tiles_y; tile += tile_step) {
+        const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+        for (uint32_t lane = 0; lane < 64; lane++) {
+            const uint32_t i = tx * 8u + (lane & 7u), j = ty * 8u + (lane >> 3);
+            if (i >= p->width || j >= p->height) continue;
+            trace.push_back(0xFD);
+            for (uint32_t k = 0; k < p->spp; k++) {
+                trace.push_back(0xFE);
+                int prim;
+                g_leaf_tests = 0;
+                (void)sample_radiance(sc, c, i, j, j * p->width + i, p->sample_offset + k, p->max_depth, (uint32_t)p->seed, (uint32_t)(p->seed >> 32), stack, cnt, prim);
+            }
+        }
+    }
+    g_trace = nullptr;
+    FILE *f = fopen(path, "wb");
+    if (!f) return CRT_ERR_IO;
+    const bool ok = fwrite(trace.data(), 1, trace.size(), f) == trace.size();
+    fclose(f);
+    return ok ? CRT_OK : CRT_ERR_IO;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Study: how much of the primary rays' traversal a per-pixel ENTRY POINT would save.  For every
+// sampled pixel: the inner nodes its spp primary rays visit; the entry point is the deepest node such that every visited
+// node lies on the path root -> entry or below the entry (no ray of the pixel enters a sibling on the way down).  Starting
+// the pixel's primary walks there skips depth(entry) node steps per walking ray; rays that miss the root box pay one step.
+// out[0] primary rays, [1] of them walking, [2] their node steps, [3] node steps saved, [4] steps added (non-walking rays of
+// pixels with an entry point), [5] pixels, [6] pixels without any walking ray, [7] sum of entry depths over pixels with one.
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int hostsim_entry_point_study(const crt_scene *s, const crt_camera *cam, const crt_render_params *p, uint32_t tile_step, uint64_t *out)
+{
+    if (!s || !s->prepared || !cam || !p || !out || tile_step == 0) return CRT_ERR_INVALID;
+    std::vector<Sphere> spheres;
+    const SceneView sc = host_view(s, spheres);
+    const CameraPOD &c = *reinterpret_cast<const CameraPOD *>(cam);
+    const uint32_t nn = sc.nnodes;
+    std::vector<int> parent(nn, -1), depth(nn, 0);
+    for (uint32_t n = 0; n < nn; n++) // breadth-first numbering: parents come before children
+        for (int k = 0; k < 2; k++) {
+            const int ref = f2i(sc.nodes[4 * n + k].w);
+            if (is_inner(ref)) { parent[ref] = (int)n; depth[ref] = depth[n] + 1; }
+        }
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    HostCounters cnt;
+    ArrayStack stack;
+    std::vector<uint32_t> mark(nn, 0);
+    uint32_t stamp = 0;
+    const uint32_t tiles_x = (p->width + 7u) / 8u, tiles_y = (p->height + 7u) / 8u;
+    for (uint32_t tile = 0; tile < tiles_x * tiles_y; tile += tile_step) {
+        const uint32_t tx = tile % tiles_x, ty = tile / tiles_x;
+        for (uint32_t lane = 0; lane < 64; lane++) {
+            const uint32_t i = tx * 8u + (lane & 7u), j = ty * 8u + (lane >> 3);
+            if (i >= p->width || j >= p->height) continue;
+            stamp++;
+            std::vector<int> visited;
+            uint64_t walking = 0, steps = 0;
+            for (uint32_t k = 0; k < p->spp; k++) {
+                f3 o, d;
+                camera_ray(c, i, j, j * p->width + i, p->sample_offset + k, (uint32_t)p->seed, (uint32_t)(p->seed >> 32), o, d);
+                Search q; q.t = FLT_MAX; q.code = -1; q.mat = 0; q.rank = 0; q.near_tie = false;
+                Trav tv;
+                trav_begin<MODE_CLOSEST>(sc, o, d, 0.001f, q, 0, 0.0f, tv, stack, cnt);
+                if (tv.cur != CRT_BVH_NONE) walking++;
+                while (tv.cur != CRT_BVH_NONE) {
+                    while (is_inner(tv.cur)) {
+                        if (mark[tv.cur] != stamp) { mark[tv.cur] = stamp; visited.push_back(tv.cur); }
+                        steps++;
+                        trav_inner(sc, tv, stack, cnt);
+                    }
+                    if (tv.cur < 0) trav_leaf<MODE_CLOSEST>(sc, o, d, 0.001f, q, 0, 0.0f, tv, stack, cnt);
+                }
+            }
+            out[0] += p->spp; out[1] += walking; out[2] += steps; out[5]++;
+            if (!walking) { out[6]++; continue; }
+            // entry point: go down from the root while exactly one inner child was visited and ... (a leaf child may have been
+            // entered too: then the walk must start here)
+            int ep = sc.root_ref;
+            for (;;) {
+                int visited_children = 0, next = -1;
+                bool leaf_child = false;
+                for (int k = 0; k < 2; k++) {
+                    const int ref = f2i(sc.nodes[4 * (size_t)ep + k].w);
+                    if (is_inner(ref)) { if (mark[ref] == stamp) { visited_children++; next = ref; } }
+                    else leaf_child = true; // cannot tell from the marks whether the leaf was entered: stay conservative
+                }
+                if (visited_children != 1 || leaf_child) break;
+                ep = next;
+            }
+            out[3] += walking * (uint64_t)depth[ep];
+            out[4] += depth[ep] ? (p->spp - walking) : 0;
+            out[7] += (uint64_t)depth[ep];
+        }
+    }
+    return CRT_OK;
+}
