@@ -22,6 +22,8 @@ static uint32_t SPP = 64, CHUNK = 2;
 // cost model (issue cycles per wave)
 static double C_A = 2130, C_VOTE = 45, C_NODE = 210, C_LEAF0 = 150, C_LEAFK = 130, C_SWAP = 150;
 static int STEPS_PER_VOTE = 4;
+static int PEEL = 0; // study: the walk's first node step (the root node) done by the shade phase, whose cost grows by C_PEEL
+static double C_PEEL = 110;
 
 struct Ctx {
     int state = 0;               // 0 needs a unit, 1 ready for the shade phase (hit resolved / new sample), 2 walking, 3 fresh (a ray waiting to walk), 4 done
@@ -53,7 +55,8 @@ static void shade(Ctx &c, Queue &q, uint64_t &blk_next, uint64_t &blk_end, bool 
         c.started = true;
         c.step = 0;
         const Seg &s = cur_seg(c);
-        c.state = s.n ? 2 : 1; // walks, or misses the root box: ready again at once
+        if (PEEL && s.n && steps[s.first] == 1) c.step = 1; // the root node's step was done inside the shade phase
+        c.state = c.step < s.n ? 2 : 1; // walks, or misses the root box: ready again at once
         return;
     }
 }
@@ -66,7 +69,9 @@ int main(int argc, char **argv)
     std::vector<uint8_t> raw;
     { uint8_t buf[1 << 16]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) raw.insert(raw.end(), buf, buf + n); }
     fclose(f);
-    const int policy = atoi(argv[2]), T = atoi(argv[3]), R = argc > 4 ? atoi(argv[4]) : 8;
+    const int policy = atoi(argv[2]) % 10, T = atoi(argv[3]), R = argc > 4 ? atoi(argv[4]) : 8;
+    PEEL = atoi(argv[2]) / 10; // policy 10: the shipped schedule with the root node's step peeled into the shade phase
+    if (PEEL) C_A += C_PEEL;
     for (size_t i = 0; i < raw.size(); i++) {
         const uint8_t b = raw[i];
         if (b == 0xFD) continue;
