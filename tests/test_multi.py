@@ -137,3 +137,55 @@ def test_reference_style_driver_with_gpus_flag(oracle, scenes, tmp_path):
         raw = open(tmp_path / "output.ppm", "rb").read()
         img = np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(H, W, 3)
         assert np.array_equal(img, want), gpus
+
+
+@pytest.mark.gpu
+def test_multi_and_noalloc_argument_errors(capi, scenes):
+    """Error behaviour of the round-2 entry points: every misuse returns a code and a message, nothing is rendered."""
+    import torch
+    desc = scenes.cat()
+    single = scenes.build(desc, 0)
+    _, cam = scenes.make_camera(64)
+    out = torch.zeros(36 * 64 * 3, dtype=torch.float32, device="cuda")
+    with pytest.raises(capi.CrtError) as e:                       # crt_render_multi needs crt_scene_commit_devices
+        single.render(cam, 64, 36, 2, multi=capi.MULTI_TILE)
+    assert e.value.code == capi.CRT_ERR_INVALID and "crt_scene_commit_devices" in str(e.value)
+    s = _commit(scenes, capi, desc, [0, 0, 0])
+    for kw, needle in [(dict(tile_rank=1, tile_ranks=3), "partitions the frame itself"), (dict(flags=capi.OUT_ACCUM), "partitions the frame itself"),
+                       (dict(multi=7), "unknown mode")]:
+        mode = kw.pop("multi", capi.MULTI_TILE)
+        with pytest.raises(capi.CrtError) as e:
+            s.render(cam, 64, 36, 2, multi=mode, **kw)
+        assert e.value.code == capi.CRT_ERR_INVALID and needle in str(e.value), (kw, str(e.value))
+    with pytest.raises(capi.CrtError) as e:                       # 4 samples do not split over 3 ranks
+        s.render(cam, 64, 36, 4, multi=capi.MULTI_SAMPLE)
+    assert "multiple of the number of ranks" in str(e.value)
+    with pytest.raises(capi.CrtError) as e:
+        s.commit_devices([0, 99])
+    assert e.value.code == capi.CRT_ERR_NO_DEVICE
+    with pytest.raises(capi.CrtError) as e:
+        s.commit_devices([])
+    assert e.value.code == capi.CRT_ERR_INVALID
+    # after a failed commit the handle is uncommitted, and says so
+    with pytest.raises(capi.CrtError):
+        s.render(cam, 64, 36, 1)
+    # crt_render_noalloc: same parameter checks as crt_render
+    with pytest.raises(capi.CrtError) as e:
+        capi.render_noalloc(single, cam, 64, 36, 3, out.data_ptr(), sample_chunks=2)
+    assert e.value.code == capi.CRT_ERR_INVALID and "sample_chunks" in str(e.value)
+    with pytest.raises(capi.CrtError) as e:
+        capi.render_noalloc(single, cam, 0, 36, 1, out.data_ptr())
+    assert e.value.code == capi.CRT_ERR_INVALID
+    # the tuning knobs are read at commit: without a reload a changed environment changes nothing
+    os.environ["CRT_KERNEL"] = "1"
+    try:
+        was = capi.RELOAD_TUNING_EACH_RENDER
+        capi.RELOAD_TUNING_EACH_RENDER = False
+        a = single.render(cam, 64, 36, 2)[0]
+        single.reload_tuning()                                    # now the pool kernel renders: same image, bit for bit
+        b = single.render(cam, 64, 36, 2)[0]
+        assert np.array_equal(a, b)
+    finally:
+        capi.RELOAD_TUNING_EACH_RENDER = was
+        del os.environ["CRT_KERNEL"]
+        single.reload_tuning()
