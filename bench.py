@@ -114,9 +114,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames-in-flight", type=int, choices=[1, 2], default=2,
-                    help="2: consecutive frames alternate between two HIP streams (dist.py), so one frame's last waves drain while the next "
-                         "frame's first waves start; 1: one frame at a time")
+    ap.add_argument("--frames-in-flight", type=int, choices=[0, 1, 2, 3], default=0,
+                    help="n > 1: consecutive frames rotate over n HIP streams (dist.py), so one frame's last waves drain while the next "
+                         "frame's first waves start; 1: one frame at a time; 0 (default): 2, and 3 when 4 or more ranks share the "
+                         "frame (a rank's share is then short against the kernel's ramp-up and drain: tools/rank_share.py, DESIGN.md section 5)")
     ap.add_argument("--mode", choices=["tile", "sample"], default="tile")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cats")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug; invalidates the headline number)")
@@ -129,6 +130,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    in_flight = args.frames_in_flight or (2 if world < 4 else 3)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
@@ -152,13 +154,13 @@ def main():
     while spp % chunks:
         chunks //= 2
     if args.mode == "tile":
-        frame = TileFrame(W, H, world, rank, device, sample_chunks=chunks, pipelined=args.frames_in_flight == 2)
+        frame = TileFrame(W, H, world, rank, device, sample_chunks=chunks, pipelined=in_flight if in_flight > 1 else False)
 
         def launch(want_stats=False, flags=0):
             return frame.render_local(scene, cam, spp, depth, seed, want_stats=want_stats, flags=flags)
         finish = frame.gather_async  # two frames in flight on two streams (dist.py): drain() completes the last ones
     else:
-        frame = SampleFrame(W, H, spp, world, rank, device, sample_chunks=chunks, pipelined=args.frames_in_flight == 2)
+        frame = SampleFrame(W, H, spp, world, rank, device, sample_chunks=chunks, pipelined=in_flight if in_flight > 1 else False)
 
         def launch(want_stats=False, flags=0):
             return frame.render_local(scene, cam, depth, seed, want_stats=want_stats, flags=flags)

@@ -40,13 +40,17 @@ class _Slots:
     scratch set per stream, which is what allows two renders to overlap.)"""
 
     def __init__(self, device, pipelined):
+        # pipelined: False / True (two frames in flight) / an integer number of frames in flight (render streams).  A rank's
+        # share of a frame shrinks with the number of ranks while the kernel's ramp-up and drain do not: measured on one GPU
+        # (tools/rank_share.py), three render streams instead of two are 2 % slower on a whole frame and 1.0 / 1.5 / 2.6 %
+        # faster on 1/2, 1/4, 1/8 of it.
         self.device = torch.device(device)
         self.gpu = self.device.type == "cuda"
         self.pipelined = bool(pipelined)
-        self.n = 4 if pipelined else 1           # buffer sets
-        self.in_flight = 2 if pipelined else 1   # render streams
-        on_gpu = self.gpu and pipelined
-        self.render_streams = [torch.cuda.Stream(self.device) for _ in range(2)] if on_gpu else [None]
+        self.in_flight = (2 if pipelined is True else int(pipelined)) if pipelined else 1   # render streams
+        self.n = self.in_flight + 2 if pipelined else 1                                    # buffer sets
+        on_gpu = self.gpu and self.pipelined
+        self.render_streams = [torch.cuda.Stream(self.device) for _ in range(self.in_flight)] if on_gpu else [None]
         self.epilogue = torch.cuda.Stream(self.device) if on_gpu else None
         self.done = [None] * self.n  # per buffer set: event after the last thing that used it
         self.k = 0                   # frames started
@@ -65,7 +69,7 @@ class _Slots:
 
     def begin(self):
         """Start frame k: returns (buffer set, render stream).  The render stream first waits for what the caller enqueued so
-        far (uploads, ...) and for the last user of the buffer set (frame k - 4's epilogue)."""
+        far (uploads, ...) and for the last user of the buffer set (the epilogue of frame k - number of buffer sets)."""
         slot, st = self.slot, self.render_stream()
         if st is not None:
             st.wait_stream(torch.cuda.current_stream(self.device))

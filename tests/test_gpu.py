@@ -352,19 +352,20 @@ def test_pipelined_tile_gather_over_rccl_single_rank(scenes, gpu_scenes, capi):
         kw["pg_options"] = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev, **kw)
     try:
-        f = TileFrame(W, H, 1, 0, dev, sample_chunks=2, pipelined=True, force_collective=True)
-        seeds, got = (3, 5, 7, 11, 13, 1984), []   # six frames over four buffer sets: two sets are used twice
-        for seed in seeds:
-            f.render_local(s, cam, spp, 10, seed)
-            f.gather_async()
-            with torch.cuda.stream(f.slots.epilogue):   # the frame is complete on the epilogue stream (drain() hands it to the caller's)
-                got.append(f.frame.clone())
-        last = f.drain().clone()
-        torch.cuda.synchronize()
-        for seed, frame in zip(seeds, got):
-            want = s.render(cam, W, H, spp, seed=seed, sample_chunks=2)[0]
-            assert np.array_equal(frame.cpu().numpy().reshape(want.shape), want), seed
-        assert np.array_equal(last.cpu().numpy().reshape(want.shape), want)
+        for in_flight in (True, 3):   # two frames in flight (one GPU's default) and three (bench.py's default when ranks share a frame)
+            f = TileFrame(W, H, 1, 0, dev, sample_chunks=2, pipelined=in_flight, force_collective=True)
+            seeds, got = (3, 5, 7, 11, 13, 1984, 2, 17), []   # eight frames over four or five buffer sets: every set is used at least once more
+            for seed in seeds:
+                f.render_local(s, cam, spp, 10, seed)
+                f.gather_async()
+                with torch.cuda.stream(f.slots.epilogue):   # the frame is complete on the epilogue stream (drain() hands it to the caller's)
+                    got.append(f.frame.clone())
+            last = f.drain().clone()
+            torch.cuda.synchronize()
+            for seed, frame in zip(seeds, got):
+                want = s.render(cam, W, H, spp, seed=seed, sample_chunks=2)[0]
+                assert np.array_equal(frame.cpu().numpy().reshape(want.shape), want), (in_flight, seed)
+            assert np.array_equal(last.cpu().numpy().reshape(want.shape), want)
         # and without a collective: two frames in flight straight into the frame buffers
         g = TileFrame(W, H, 1, 0, dev, sample_chunks=2, pipelined=True)
         for seed in seeds:

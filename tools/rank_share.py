@@ -1,6 +1,6 @@
 """What one rank of an N-way tile partition costs on this GPU: the headline frame's tiles k = rank (mod N), compact output,
-K frames back to back, against 1/N of the whole frame.  Each case is timed with one frame at a time on one stream and with two frames in flight on two streams.
-usage: rank_share.py [N] [chunks]"""
+K frames back to back, against 1/N of the whole frame.  Each case is timed with n frames in flight on n streams, n from INFLIGHT (default 1,2).
+usage: [INFLIGHT=1,2,3] rank_share.py [N] [chunks]"""
 import sys, time
 sys.path.insert(0, '.')
 import torch
