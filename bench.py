@@ -43,7 +43,10 @@ VALU_PEAK_TLANEOPS_256CU = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0          # aggregate L2, same guide
 INFINITY_CACHE_GATHER_GBS = 8600.0  # random 1 KB-row gathers from a 38 MB table (Infinity Cache resident), same guide
-DEFAULT_CHUNKS = 32  # same for every N: 1/8 of the frame per rank needs fine units (tools/rank_share.py), the whole frame does not mind
+# One sample per chunk at the headline's 64 spp: the finalize pass then adds single samples in sample order, which is the
+# reference's own loop (renderer.h:26-32), so the timed frame is bit-identical to the whole-pixel one
+# (tests/test_gpu.py::test_one_sample_per_chunk_is_the_sequential_sum, also at the full 1080p x 64 spp).  Same for every N.
+DEFAULT_CHUNKS = 64
 
 
 def lane_ops(st):
@@ -107,6 +110,20 @@ def cpu_baseline(desc, cam_params, width, height, max_depth, seed, target_second
                        % (width, height, spp - 1, st.rays, reps, sorted(secs)[len(secs) // 2], cores),
                 reference_traversal={"box_tests_per_ray": st.box_tests / max(st.rays, 1), "triangle_tests_per_ray": st.tri_tests / max(st.rays, 1),
                                      "sphere_tests_per_ray": st.sphere_tests / max(st.rays, 1)})
+
+
+def image_note(chunks, unit_spp, sample_split=False):
+    """What the timed frame is, against the reference's sequential sample-order sum (renderer.h:26-32)."""
+    if sample_split:
+        return ("sample split: every rank sums its own samples, the ranks' sums are added in rank order; same samples as the reference's "
+                "sequential sum, differs from it by float association only (rtol 3e-7 on the gamma-encoded value, tests/test_dist.py)")
+    if chunks <= 1:
+        return "bit-exact: every pixel's samples summed in sample order (renderer.h:28-32)"
+    if chunks == unit_spp:
+        return ("bit-exact: one sample per work unit, the %d single-sample slabs of a pixel added in sample order starting from 0 -- the float "
+                "operations of the reference's loop (renderer.h:26-32); equal to the whole-pixel frame bit for bit, tested at this size" % chunks)
+    return ("chunked-sum variant: same samples, each pixel's %d chunk sums added in chunk order; differs from the reference's sequential "
+            "sample-order sum by float association only (<= 3e-7 relative, tests/test_gpu.py); --chunks 1 or --chunks <spp> are bit-exact" % chunks)
 
 
 def main():
@@ -237,9 +254,7 @@ def main():
             "config": {"workload": "%s %dx%d %dspp depth %d (models/%s + ground + emissive sphere, seed %d)" %
                        (args.workload, W, H, spp, depth, {"cats": "cats.obj", "random_spheres": "no mesh"}.get(builder, "cat.obj"), seed),
                        "partition": "%s x%d" % (args.mode, world), "frames_in_flight": frame.slots.in_flight, "sample_chunks": used_chunks,
-                       "image": ("chunked-sum variant: same samples, each pixel's %d chunk sums added in chunk order; differs from the reference's "
-                                 "sequential sample-order sum by float association only (<= 3e-7 relative, tests/test_gpu.py); --chunks 1 is the bit-exact one"
-                                 % used_chunks) if used_chunks > 1 else "bit-exact: every pixel's samples summed in sample order (renderer.h:28-32)",
+                       "image": image_note(used_chunks, spp if args.mode == "tile" else spp // world, args.mode == "sample" and world > 1),
                        "triangles": info.num_triangles, "bvh_nodes": info.num_nodes, "bvh_depth": info.bvh_depth,
                        "rays_per_frame": int(rays_frame), "device_cus": cus},
             "roofline": {"bound": "valu", "achieved": ops / ksec / 1e12, "peak": valu_peak, "unit": "Tlane-op/s",

@@ -792,9 +792,8 @@ static int enqueue_render(const crt_scene *s, const DeviceScene &d, const crt_ca
     ra.node_cache = (uint32_t)t.node_cache;
     ra.blocks_per_stripe = t.stripe_bands ? 1u : 0u; // bands by default (+0.5 % cats, +2 % on the 1 M-triangle grid); launch_render sets the count
     ra.chunks = chunks;
-    ra.chunk_stride = (uint32_t)(rgb_floats / 3);
     float *d_target = d_rgb;
-    if (chunks > 1) { d_target = d_slabs; ra.flags |= (uint32_t)RA_ACCUM; } // raw chunk sums into one slab per chunk
+    if (chunks > 1) { d_target = d_slabs; ra.flags |= (uint32_t)RA_ACCUM; } // raw chunk sums, [pixel][chunk][3]
     HIP_TRY(hipMemsetAsync(d_counters, 0, CRT_COUNTER_BYTES, stream));
     if (ev0) HIP_TRY(hipEventRecord(ev0, stream));
     HIP_TRY(launch_render(d.view, *reinterpret_cast<const CameraPOD *>(cam), ra, d_target, d_ids, d_counters, (p->flags & CRT_COUNT_WORK) != 0,
@@ -803,6 +802,9 @@ static int enqueue_render(const crt_scene *s, const DeviceScene &d, const crt_ca
     if (chunks > 1) HIP_TRY(launch_finalize_chunks(d_slabs, chunks, rgb_floats, p->spp, (p->flags & CRT_OUT_ACCUM) != 0, d_rgb, stream));
     return CRT_OK;
 }
+
+// floats of chunk scratch a frame needs: blocks of 64 pixels x chunks x 64 x 3 (crt_kernels.hip: finalize_chunks_kernel)
+static size_t chunk_slab_floats(size_t rgb_floats, uint32_t chunks) { return (rgb_floats / 3 + 63) / 64 * 192 * chunks; }
 
 // The scratch set of `stream` on `d`, with counters, events and (sample chunks) slabs of the size this frame needs.
 static int acquire_scratch(DeviceScene &d, hipStream_t stream, uint32_t chunks, size_t rgb_floats, StreamScratch **out)
@@ -817,7 +819,7 @@ static int acquire_scratch(DeviceScene &d, hipStream_t stream, uint32_t chunks, 
         HIP_TRY(hipEventCreate(&x->ev_done));
     }
     if (chunks > 1) {
-        const size_t need = rgb_floats * chunks;
+        const size_t need = chunk_slab_floats(rgb_floats, chunks);
         if (x->chunk_slab_floats < need) {
             if (x->d_chunk_slabs) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(x->d_chunk_slabs); }
             x->d_chunk_slabs = nullptr; x->chunk_slab_floats = 0;
@@ -933,8 +935,8 @@ extern "C" int crt_render_noalloc(const crt_scene *cs, const crt_camera *cam, co
     unsigned char *scratch = (unsigned char *)noalloc_scratch_ptr(d.device);
     if (!scratch) return fail(CRT_ERR_HIP, "crt_render_noalloc: the static scratch of this device was not set up at commit");
     const size_t rgb_floats = output_floats(p);
-    if (chunks > 1 && (uint64_t)rgb_floats * chunks * sizeof(float) > (uint64_t)CRT_NOALLOC_SLAB_BYTES)
-        return fail(CRT_ERR_LIMIT, "crt_render_noalloc: output floats x sample_chunks x 4 exceeds the static scratch (CRT_NOALLOC_SLAB_BYTES = 32 MiB); "
+    if (chunks > 1 && (uint64_t)chunk_slab_floats(rgb_floats, chunks) * sizeof(float) > (uint64_t)CRT_NOALLOC_SLAB_BYTES)
+        return fail(CRT_ERR_LIMIT, "crt_render_noalloc: output floats (pixels rounded up to a multiple of 64) x sample_chunks x 4 exceeds the static scratch (CRT_NOALLOC_SLAB_BYTES = 32 MiB); "
                                    "use fewer sample_chunks (1 needs no slab) or crt_render");
     HIP_TRY(hipSetDevice(d.device));
     hipStream_t stream = (hipStream_t)p->stream;
@@ -1199,7 +1201,7 @@ extern "C" int crt_render_multi(const crt_scene *cs, const crt_camera *cam, cons
     if (m.done_recorded[set ^ 1]) HIP_TRY(hipStreamWaitEvent(rs, m.frame_done[set ^ 1], 0));
     if (mode == CRT_MULTI_TILE) HIP_TRY(launch_untile(d_all, p->width, p->height, n, d_rgb, rs));
     else if (m.use_rccl) HIP_TRY(launch_finalize(d_all, frame_floats, p->spp, d_rgb, rs));
-    else HIP_TRY(launch_finalize_chunks(d_all, n, frame_floats, p->spp, false, d_rgb, rs)); // the n sums added in rank order, /spp, gamma
+    else HIP_TRY(launch_sum_frames(d_all, n, frame_floats, p->spp, false, d_rgb, rs)); // the n sums added in rank order, /spp, gamma
     if (out_ids && n > 1) { // other ranks wrote ids into the root's buffer from their own streams
         for (uint32_t r = 1; r < n; r++) {
             if (m.use_rccl) { // (copy transport: sent[r] already covers rank r's render)

@@ -25,7 +25,6 @@ struct RenderArgs {
     uint32_t tiles_x_magic;   // floor(2^32 / tiles_x) for the kernel's tile -> (column, row) division (set by launch_render)
     uint32_t blocks_per_stripe; // in: non-zero = each block counter owns a contiguous band of the frame; launch_render sets the count
     uint32_t node_cache;      // four waves per workgroup sharing an LDS copy of the top of the tree (trees up to 24 deep): 0 never, 1 when the frame fills the GPU, 2 always
-    uint32_t chunk_stride;    // pixels per chunk slab of the scratch the kernel writes when chunks > 1
     uint32_t kernel;          // RK_*
     uint32_t bvh_depth;       // levels of the triangle BVH (selects the LDS stack size)
 };
@@ -54,7 +53,8 @@ void *noalloc_scratch_ptr(int device);
 hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,
                          bool count_work, uint32_t max_waves, hipStream_t stream);
 hipError_t launch_untile(const float *compact_all, uint32_t width, uint32_t height, uint32_t tile_ranks, float *out, hipStream_t stream);
-hipError_t launch_finalize_chunks(const float *slabs, uint32_t chunks, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream);
+hipError_t launch_finalize_chunks(const float *slabs, uint32_t chunks, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream); // slabs [64-pixel block][chunk][64][3], n = 3 x pixels
+hipError_t launch_sum_frames(const float *frames, uint32_t count, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream);      // frames n floats apart
 hipError_t launch_quantize(const float *rgb, size_t n, uint8_t *out, hipStream_t stream);
 hipError_t launch_finalize(const float *accum, size_t n, uint32_t total_spp, float *out, hipStream_t stream);
 

@@ -88,7 +88,14 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
 
 // renderer.h:36-37 + color.h:5-24: average, gamma, store (or the raw sum in accumulate mode)
 // chunk / first_sample: the part of the pixel's samples this lane rendered (sample chunks: RenderArgs.chunks > 1; then
-// the launcher has set RA_ACCUM and `out` is the chunk scratch, one frame-sized slab per chunk)
+// the launcher has set RA_ACCUM and `out` is the chunk scratch, see finalize_chunks_kernel)
+// where pixel (or compact slot) px, chunk c goes in the chunk scratch, in units of 3 floats: [px / 64][c][px % 64]; with one
+// chunk (shift 0) this is px itself, the frame's own layout
+__device__ __forceinline__ size_t chunk_slot(uint32_t px, uint32_t chunk, uint32_t chunk_shift)
+{
+    return ((size_t)px << chunk_shift) | chunk;
+}
+
 __device__ __forceinline__ void store_pixel(const RenderArgs &ra, float *__restrict__ out, int *__restrict__ ids, uint32_t q, uint32_t pixel, f3 col,
                                             int primary, uint32_t chunk = 0, uint32_t first_sample = 0, uint32_t nsamples = 0xFFFFFFFFu)
 {
@@ -99,7 +106,8 @@ __device__ __forceinline__ void store_pixel(const RenderArgs &ra, float *__restr
         o.y = o.y > 0 ? __builtin_sqrtf(o.y) : 0.0f;
         o.z = o.z > 0 ? __builtin_sqrtf(o.z) : 0.0f;
     }
-    const size_t idx = (size_t)chunk * ra.chunk_stride + ((ra.flags & RA_COMPACT) ? (size_t)q : (size_t)pixel);
+    const uint32_t px = (ra.flags & RA_COMPACT) ? q : pixel;
+    const size_t idx = chunk_slot(px, chunk, ra.chunk_shift);
     out[3 * idx + 0] = o.x; out[3 * idx + 1] = o.y; out[3 * idx + 2] = o.z;
     const uint32_t n = nsamples == 0xFFFFFFFFu ? ra.spp : nsamples, first = ra.sample_offset + first_sample;
     if (ids && ra.ids_sample >= first && ra.ids_sample - first < n) ids[pixel] = primary;
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                             phase = P_NEW;
                         } else { // outside the image (ragged last tile column / row): nothing to render, fetch again next time
                             if (rak.flags & RA_COMPACT) {
-                                const size_t z = (size_t)chunk * rak.chunk_stride + slot;
+                                const size_t z = chunk_slot(slot, chunk, rak.chunk_shift);
                                 out[3 * z + 0] = 0.0f; out[3 * z + 1] = 0.0f; out[3 * z + 2] = 0.0f;
                             }
                             q = NO_PIXEL;
@@ -938,19 +946,61 @@ __global__ __launch_bounds__(256) void finalize_kernel(const float *__restrict__
     out[k] = v > 0 ? __builtin_sqrtf(v) : 0.0f;
 }
 
-// sample chunks: out[k] = finish(((slab 0 + slab 1) + slab 2) + ...), finish = identity (raw sums) or /spp and gamma
-__global__ __launch_bounds__(256) void finalize_chunks_kernel(const float *__restrict__ slabs, uint32_t chunks, size_t n, float spp, int raw,
-                                                              float *__restrict__ out)
+// sample-split frames of several ranks on one device: out[k] = finish(((frame 0 + frame 1) + frame 2) + ...), frames n floats
+// apart, finish = identity (raw sums) or /spp and gamma
+__global__ __launch_bounds__(256) void sum_frames_kernel(const float *__restrict__ frames, uint32_t count, size_t n, float spp, int raw,
+                                                         float *__restrict__ out)
 {
     const size_t k = (size_t)blockIdx.x * 256u + threadIdx.x;
     if (k >= n) return;
-    float v = slabs[k];
-    for (uint32_t c = 1; c < chunks; c++) v = v + slabs[(size_t)c * n + k];
+    float v = frames[k];
+    for (uint32_t c = 1; c < count; c++) v = v + frames[(size_t)c * n + k];
     if (!raw) {
         v = v / spp;
         v = v > 0 ? __builtin_sqrtf(v) : 0.0f;
     }
     out[k] = v;
+}
+
+// sample chunks: `slabs` is [block of 64 pixels][chunk][pixel in block][3].  The lanes that render a pixel's chunks sit in
+// the same wave and neighbouring pixels in the same or the next waves, so the 12-byte stores of a 48 KB block arrive close
+// together and its cache lines are complete before they leave the L2 (one frame-sized slab per chunk, the first layout,
+// wrote 1.8 bytes per payload byte); and thread r of a 192-thread block reads float r of every chunk row: 768 contiguous
+// bytes per block and chunk, no LDS -- this pass runs beside the next frame's render kernel, which leaves ~10 KB of a CU's LDS
+// free, and a staged version that needed 49 KB per block kept that kernel's workgroups off the CUs (+10 % per step).
+// out[pixel][ch] = finish((((0 + chunk 0) + chunk 1) + ...): the sum starts at 0 like the reference's pixel_color
+// (renderer.h:26), so with one sample per chunk the float operations are the sequential loop's own and the frame is
+// bit-identical to the whole-pixel one.
+__device__ __forceinline__ float finish_channel(float v, float spp, int raw)
+{
+    if (raw) return v;
+    v = v / spp;
+    return v > 0 ? __builtin_sqrtf(v) : 0.0f;
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(32))) void finalize_chunks_kernel(const float *__restrict__ slabs, uint32_t chunk_shift, size_t npixels, float spp, int raw,
+                                                             float *__restrict__ out)
+{
+    const size_t pixel = (size_t)blockIdx.x * 64u + threadIdx.x;
+    if (pixel >= npixels) return;
+    const uint32_t chunks = 1u << chunk_shift;
+    const float *row = slabs + (pixel << chunk_shift) * 3u;
+    float r = 0.0f, g = 0.0f, b = 0.0f;
+    if (chunk_shift >= 2u) { // four chunks = 48 bytes = three 16-byte loads (the row starts at a multiple of 48 bytes)
+        const v4f *q = reinterpret_cast<const v4f *>(row);
+#pragma unroll 1
+        for (uint32_t c = 0; c < chunks; c += 4u, q += 3) {
+            const v4f x = q[0], y = q[1], z = q[2];
+            r = r + x.x; g = g + x.y; b = b + x.z;
+            r = r + x.w; g = g + y.x; b = b + y.y;
+            r = r + y.z; g = g + y.w; b = b + z.x;
+            r = r + z.y; g = g + z.z; b = b + z.w;
+        }
+    } else {
+        for (uint32_t c = 0; c < chunks; c++) { r = r + row[3u * c]; g = g + row[3u * c + 1u]; b = b + row[3u * c + 2u]; }
+    }
+    out[3u * pixel + 0u] = finish_channel(r, spp, raw);
+    out[3u * pixel + 1u] = finish_channel(g, spp, raw);
+    out[3u * pixel + 2u] = finish_channel(b, spp, raw);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -992,8 +1042,20 @@ void *noalloc_scratch_ptr(int device)
 
 hipError_t launch_finalize_chunks(const float *slabs, uint32_t chunks, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream)
 {
+    uint32_t shift = 0;
+    while ((1u << shift) < chunks) shift++;
+    const size_t npixels = n / 3;
+    const uint32_t blocks = (uint32_t)((npixels + 63) / 64);
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(finalize_chunks_kernel, dim3(blocks), dim3(64), 0, stream, slabs, shift, npixels, (float)spp, raw ? 1 : 0, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum_frames(const float *frames, uint32_t count, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream)
+{
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
-    hipLaunchKernelGGL(finalize_chunks_kernel, dim3(blocks), dim3(256), 0, stream, slabs, chunks, n, (float)spp, raw ? 1 : 0, out);
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(sum_frames_kernel, dim3(blocks), dim3(256), 0, stream, frames, count, n, (float)spp, raw ? 1 : 0, out);
     return hipGetLastError();
 }
 

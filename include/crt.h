@@ -196,8 +196,8 @@ int crt_render(const crt_scene *s, const crt_camera *cam, const crt_render_param
  * library runs on, held until the process ends) whose per-device address is taken when a scene is committed to the
  * device.  The call makes no hipMalloc / hipFree / event creation and never waits on the host: everything is enqueued on
  * p->stream.  out_rgb and out_ids (nullable) must be device pointers; out_rays (nullable, device pointer) receives the
- * frame's path-segment count.  Limits: with sample_chunks > 1, output floats x sample_chunks x 4 bytes must fit the
- * 32 MiB of slabs (CRT_ERR_LIMIT otherwise; sample_chunks <= 1 needs no slab and has no size limit).  There is no
+ * frame's path-segment count.  Limits: with sample_chunks > 1, output pixels (rounded up to a multiple of 64) x 3 x sample_chunks x 4 bytes
+ * must fit the 32 MiB of slabs (CRT_ERR_LIMIT otherwise; sample_chunks <= 1 needs no slab and has no size limit).  There is no
  * crt_stats and no CRT_COUNT_WORK readout.  Every call on a GPU shares that GPU's array: the call clears what must start
  * at zero, and two calls whose kernels overlap on one GPU (different streams) race -- keep them on one stream. */
 #define CRT_NOALLOC_SLAB_BYTES (32u << 20)

@@ -244,6 +244,25 @@ def test_sample_chunks_match_chunked_sum_of_oracle(oracle, scenes, gpu_scenes, n
     assert np.array_equal(full.reshape(expect.shape), expect)
 
 
+@pytest.mark.parametrize("name,width,height,spp", [("cats", 97, 45, 8), ("cat_checker", 64, 36, 4), ("cats", 43, 19, 64)])
+def test_one_sample_per_chunk_is_the_sequential_sum(oracle, scenes, gpu_scenes, name, width, height, spp):
+    """sample_chunks = spp: every work unit is one sample, the finalize pass adds a pixel's single-sample slabs in sample
+    order starting from 0 -- the float operations of the reference's loop (renderer.h:26-32).  So the frame must be the
+    oracle's image (the sequential sum) bit for bit, ids and ray count included: the parallel decomposition bench.py times
+    costs no exactness.  Ragged frame sizes, raw sums and compact tile lists as well."""
+    from cudaraytracer_amd import capi
+    desc, s = gpu_scenes(name)
+    params, cam = scenes.make_camera(width)
+    fb, ids, acc, rst = oracle.RefScene(desc).render(oracle.make_camera(params, width), width, height, spp, want_accum=True)
+    rgb, gids, st = s.render(cam, width, height, spp, want_ids=True, sample_chunks=spp)
+    assert st.rays == rst.rays and np.array_equal(gids, ids)
+    assert np.array_equal(rgb.reshape(fb.shape), fb), helpers.psnr(rgb.reshape(fb.shape), fb)
+    raw = s.render(cam, width, height, spp, flags=capi.OUT_ACCUM, sample_chunks=spp)[0]
+    assert np.array_equal(raw.reshape(acc.shape), acc)
+    parts = [s.render(cam, width, height, spp, tile_rank=r, tile_ranks=3, flags=capi.OUT_COMPACT, sample_chunks=spp)[0] for r in range(3)]
+    assert np.array_equal(helpers.untile_numpy(np.concatenate(parts), width, height, 3).reshape(fb.shape), fb)
+
+
 def test_sphere_scene_on_gpu(oracle, scenes, gpu_scenes, monkeypatch, node_cache):
     """Row N3 (scene.h:53-90): 488 spheres (487 of them sphere slots of the BVH), Lambertian / Metal / Dielectric, both
     kernels, whole pixels and sample chunks."""
@@ -494,14 +513,17 @@ def test_work_counters_equal_the_host_single_stepper(hostsim, scenes, gpu_scenes
     assert (st4.rays, st4.nodes, st4.tri_tests, st4.sphere_tests, st4.shaded_hits) == (w4["rays"], w4["nodes"], w4["tri_tests"], w4["sphere_tests"], w4["shaded_hits"])
 
 
-def test_benchmarked_configuration_at_full_size(scenes, gpu_scenes, capi):
-    """What bench.py times: cats, 1920x1080, 64 spp, sample_chunks = 32, frames alternating between two streams.  The raw
-    sums of the chunked frame must equal, bit for bit, the chunk-order float32 sum of 32 whole-pixel 2-spp renders at
-    sample_offset = 2c (each of those is the oracle-checked sequential path), and four frames issued back to back on two
-    alternating streams must all come out as that same frame."""
+@pytest.mark.parametrize("n", [64, 32])
+def test_benchmarked_configuration_at_full_size(scenes, gpu_scenes, capi, n):
+    """What bench.py times: cats, 1920x1080, 64 spp, sample_chunks = 64 (one sample per work unit; 32 was the default before
+    and stays covered), frames alternating between two streams.  The raw sums of the chunked frame must equal, bit for bit,
+    the chunk-order float32 sum of n whole-pixel renders of 64/n spp at sample_offset = c * 64/n (each of those is the
+    oracle-checked sequential path), and four frames issued back to back on two alternating streams must all come out as
+    that same frame.  With one sample per chunk the chunk-order sum IS the reference's sequential loop (renderer.h:26-32), so
+    the timed frame must also equal the whole-pixel frame (sample_chunks = 1) bit for bit, raw sums and finished image."""
     import torch
     _, s = gpu_scenes("cats")
-    W, H, spp, n = 1920, 1080, 64, 32
+    W, H, spp = 1920, 1080, 64
     _, cam = scenes.make_camera(W)
     chunked = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
     st = s.render(cam, W, H, spp, flags=capi.OUT_ACCUM | capi.OUT_DEVICE, out_rgb=chunked.data_ptr(), sample_chunks=n)[2]
@@ -529,6 +551,14 @@ def test_benchmarked_configuration_at_full_size(scenes, gpu_scenes, capi):
         st_.synchronize()
     for k in range(4):
         assert torch.equal(outs[k], frame), k
+    if n == spp:
+        whole = torch.empty_like(chunked)
+        st1 = s.render(cam, W, H, spp, flags=capi.OUT_ACCUM | capi.OUT_DEVICE, out_rgb=whole.data_ptr(), sample_chunks=1)[2]
+        torch.cuda.synchronize()
+        assert st1.rays == st.rays and torch.equal(whole, chunked)
+        s.render(cam, W, H, spp, out_rgb=whole.data_ptr(), sample_chunks=1, flags=capi.OUT_DEVICE)
+        torch.cuda.synchronize()
+        assert torch.equal(whole, frame)
 
 
 def test_host_pointer_renders_on_two_streams_from_two_threads(scenes, gpu_scenes):
