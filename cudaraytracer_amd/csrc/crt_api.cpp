@@ -240,6 +240,7 @@ struct Tuning {
     int kernel = 0;            // CRT_KERNEL: 0 render_kernel (pixel per lane), 1 render_pool_kernel (whole-pixel frames only)
     int pool_refill = 16;      // CRT_POOL_REFILL: pool kernel, free lanes that end a run of walk steps
     int sched_threshold = 44;  // CRT_SCHED_THRESHOLD: lanes that must wait for the shade phase before it runs
+    int fetch_block = 0;       // CRT_FETCH_BLOCK: work units per trip to a block counter (a power of two, 64..65536); 0: chosen per frame
     int node_cache = 1;        // CRT_NODE_CACHE: LDS copy of the top of the tree: 0 never, 1 when the frame fills the GPU, 2 always
     int stripe_bands = 1;      // CRT_STRIPE_BANDS: each block counter owns a contiguous band of the frame
     int waves_per_cu = 20;     // CRT_WAVES_PER_CU: persistent waves launched per compute unit (96 VGPRs: 5 per SIMD)
@@ -250,6 +251,7 @@ struct Tuning {
         pool_refill = std::min(std::max(get_env_int("CRT_POOL_REFILL", 16), 1), 63);
         sched_threshold = std::min(std::max(get_env_int("CRT_SCHED_THRESHOLD", 44), 1), 64);
         node_cache = std::min(std::max(get_env_int("CRT_NODE_CACHE", 1), 0), 3);
+        fetch_block = std::min(std::max(get_env_int("CRT_FETCH_BLOCK", 0), 0), 65536);
         stripe_bands = get_env_int("CRT_STRIPE_BANDS", 1) ? 1 : 0;
         waves_per_cu = std::min(std::max(get_env_int("CRT_WAVES_PER_CU", 20), 1), 64);
         print_sections = get_env_int("CRT_PRINT_SECTIONS", 0);
@@ -790,6 +792,8 @@ static int enqueue_render(const crt_scene *s, const DeviceScene &d, const crt_ca
     ra.sched_threshold = (uint32_t)(pool ? t.pool_refill : t.sched_threshold);
     ra.bvh_depth = s->bvh.depth;
     ra.node_cache = (uint32_t)t.node_cache;
+    ra.fetch_shift = 0;
+    while (t.fetch_block > 1 && (2u << ra.fetch_shift) <= (uint32_t)t.fetch_block) ra.fetch_shift++; // floor(log2); 0 = launch_render's rule
     ra.blocks_per_stripe = t.stripe_bands ? 1u : 0u; // bands by default (+0.5 % cats, +2 % on the 1 M-triangle grid); launch_render sets the count
     ra.chunks = chunks;
     float *d_target = d_rgb;

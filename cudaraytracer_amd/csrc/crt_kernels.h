@@ -27,6 +27,7 @@ struct RenderArgs {
     uint32_t node_cache;      // four waves per workgroup sharing an LDS copy of the top of the tree (trees up to 24 deep): 0 never, 1 when the frame fills the GPU, 2 always
     uint32_t kernel;          // RK_*
     uint32_t bvh_depth;       // levels of the triangle BVH (selects the LDS stack size)
+    uint32_t fetch_shift;     // log2 of the work units a wave takes from a block counter at a time; in: 0 = launch_render chooses
 };
 
 // counters: 32 x uint64 on the device: [0] rays [1] nodes [2] triangle tests [3] sphere tests [4] tie refolds [5] shaded hits [6] pixel work counter

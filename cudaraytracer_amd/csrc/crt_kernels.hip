@@ -1,7 +1,7 @@
 // crt_kernels.hip -- gfx950 kernels of the hot path and their launchers.
 //
 // render_kernel: persistent wave64 waves.  A lane owns one work unit at a time -- a pixel, or one chunk of a pixel's
-// samples -- taken in blocks of CRT_FETCH_BLOCK units from 64 striped block counters (units are numbered in 8x8-tile
+// samples -- taken in blocks of 2^fetch_shift units (RenderArgs, chosen by launch_render) from 64 striped block counters (units are numbered in 8x8-tile
 // order: the reference's block shape, kernel.cu:50-51, renderer.h:51-52); a unit's samples are summed in the lane in
 // sample order (renderer.h:28-32), so the float sum is the reference's whatever the partition.  Waves run four to a
 // workgroup and share an LDS copy of the top of the tree (CRT_NODE_CACHE_NODES = 192 nodes for trees up to 16 deep: 4 x
@@ -217,9 +217,6 @@ enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
 // vector memory instruction whatever the number of lanes) in phase B, so the code below keeps
 // scalar bookkeeping and register shuffling out of the loops, reads uniform data through scalar loads and the top of
 // the tree from LDS; what was tried and rejected is listed in DESIGN.md section 7.
-#ifndef CRT_FETCH_BLOCK
-#define CRT_FETCH_BLOCK 128u // work units per block (>= 64: one block always covers a wave's request; 128 against 64: -1.2 % whole frame, -2.9 % on 1/8 of it)
-#endif
 #ifndef CRT_WORK_STRIPES
 #define CRT_WORK_STRIPES 64u // block counters: an atomic on ONE address costs the device ~5 ns, and every wave waits its turn
 #endif
@@ -370,7 +367,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                     const uint32_t chunk = q & chunk_mask;
                     store_pixel(rak, out, ids, q >> rak.chunk_shift, pixel, col, primary, chunk, chunk * chunk_spp, chunk_spp);
                 }
-                // Units come in blocks of CRT_FETCH_BLOCK from CRT_WORK_STRIPES counters 256 B apart; block g of counter k
+                // Units come in blocks of 2^fetch_shift from CRT_WORK_STRIPES counters 256 B apart; block g of counter k
                 // is global block g * stripes + k, so all counters advance through the frame in raster order together.
                 const uint32_t total = rak.local_pixels << rak.chunk_shift;
                 const uint32_t n_need = (uint32_t)popc64(fm), left = blk_end - blk_next, rk = (uint32_t)lane_rank(fm);
@@ -379,7 +376,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                     const int leader = __builtin_ctzll(fm);
                     // blocks_per_stripe = 0: block b of counter k is global block b * stripes + k (all counters walk the frame
                     // together); else counter k owns the contiguous blocks [k * bps, (k + 1) * bps) (a band of the frame)
-                    const uint32_t bps = rak.blocks_per_stripe, nblocks = (total + CRT_FETCH_BLOCK - 1u) / CRT_FETCH_BLOCK;
+                    const uint32_t bps = rak.blocks_per_stripe, fetch_block = 1u << rak.fetch_shift, nblocks = (total + fetch_block - 1u) >> rak.fetch_shift;
                     while (stripes_left > 0) {
                         // blocks of this counter
                         const uint32_t mine = bps ? (nblocks > stripe * bps ? (nblocks - stripe * bps < bps ? nblocks - stripe * bps : bps) : 0u)
@@ -388,8 +385,8 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                         if ((int)lane == leader) b = atomicAdd(work + stripe * 64u, 1u);
                         b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
                         if (b < mine) {
-                            fresh = (bps ? stripe * bps + b : b * CRT_WORK_STRIPES + stripe) * CRT_FETCH_BLOCK;
-                            fresh_end = total - fresh > CRT_FETCH_BLOCK ? fresh + CRT_FETCH_BLOCK : total;
+                            fresh = (bps ? stripe * bps + b : b * CRT_WORK_STRIPES + stripe) << rak.fetch_shift;
+                            fresh_end = total - fresh > fetch_block ? fresh + fetch_block : total;
                             break;
                         }
                         // This counter is used up.  The wave that is the first to see that (b == mine) counts it in `used_up`;
@@ -1086,8 +1083,20 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     if (a.chunks == 0) a.chunks = 1;
     a.chunk_shift = 0;
     while ((1u << a.chunk_shift) < a.chunks) a.chunk_shift++;
+    // Work units per trip to a block counter: a power of two >= 64, so that one block always covers a wave's request.  Larger
+    // blocks mean fewer trips, smaller ones a more even end of the frame; measured at one sample per unit (headline frame,
+    // tools/fetch_block_sweep.py, ms per frame at 128 / 256 / 512 / 1024): whole frame 9.56 / 9.46 / 9.42 / 9.49, 1/2 of it
+    // 4.86 / 4.79 / 4.79 / 4.86, 1/4 2.46 / 2.42 / 2.42 / 2.49, 1/8 1.267 / 1.254 / 1.268 / 1.34.  Rule: a resident wave
+    // makes at least 8 trips per frame, blocks of 64..512 units.
+    if (a.fetch_shift == 0) {
+        const uint64_t per_wave = (uint64_t)local_tiles * 64u * a.chunks / (max_waves ? max_waves : 1u);
+        a.fetch_shift = 6;
+        while (a.fetch_shift < 9 && (16ull << a.fetch_shift) <= per_wave) a.fetch_shift++;
+    }
+    if (a.fetch_shift < 6) a.fetch_shift = 6;
+    if (a.fetch_shift > 16) a.fetch_shift = 16;
     if (a.blocks_per_stripe) { // contiguous bands: ceil(blocks / stripes)
-        const uint64_t nblocks = (((uint64_t)local_tiles * 64u * a.chunks) + CRT_FETCH_BLOCK - 1) / CRT_FETCH_BLOCK;
+        const uint64_t nblocks = (((uint64_t)local_tiles * 64u * a.chunks) + (1u << a.fetch_shift) - 1) >> a.fetch_shift;
         a.blocks_per_stripe = (uint32_t)((nblocks + CRT_WORK_STRIPES - 1) / CRT_WORK_STRIPES);
     }
     a.tiles_x_magic = a.tiles_x > 1 ? (uint32_t)((1ull << 32) / a.tiles_x) : 0xFFFFFFFFu; // tiles_x == 1: tile / 1 = tile - (0 or 1), fixed up
