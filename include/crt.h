@@ -156,7 +156,9 @@ typedef struct crt_render_params {
     uint32_t sample_chunks;       /* 0 or 1: a lane renders all spp samples of its pixel, summed in sample order
                                      (renderer.h:28-32), bit for bit.  n > 1 (a power of two dividing spp): the work unit is (pixel, chunk of
                                      spp/n consecutive samples), each chunk summed in sample order, the n chunk sums added in
-                                     order; same samples, finer load balance, sum differs by float association only       */
+                                     chunk order starting from 0: same samples, finer load balance.  n = spp (one sample per
+                                     unit) adds single samples in sample order, i.e. it is the sequential sum again, bit for
+                                     bit -- the fast exact setting; 1 < n < spp differs from it by float association only   */
     uint64_t seed;                /* Philox key; reference seed literal 1984 (renderer.h:45)                */
     void *stream;                 /* hipStream_t, NULL = default stream                                     */
 } crt_render_params;

@@ -30,9 +30,10 @@ def test_surface_compiles_and_fails_loudly_without_gpu(capi, tmp_path):
 
 
 @pytest.mark.gpu
-def test_reference_style_driver_matches_oracle(oracle, scenes, tmp_path):
+@pytest.mark.parametrize("spp", [3, 4])   # 3: whole pixels; 4 (a power of two): Renderer's default of one sample per work unit -- both bit-exact
+def test_reference_style_driver_matches_oracle(oracle, scenes, tmp_path, spp):
     assert os.path.exists(DEMO), "examples/crt_demo not built (python __graft_entry__.py)"
-    W, H, spp = 200, 120, 3
+    W, H = 200, 120
     r = subprocess.run([DEMO, os.path.join(helpers.REPO, "models", "cat.obj"), str(W), str(H), str(spp)], cwd=tmp_path, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     raw = open(tmp_path / "output.ppm", "rb").read()
