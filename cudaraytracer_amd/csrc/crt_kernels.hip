@@ -304,8 +304,11 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
     bool guard_tripped = false;
     for (uint32_t guard = 0;; guard++) {
         const bool walking = tv.cur != CRT_BVH_NONE;
-        const int nwalk = popc64(__ballot(walking));
-        const int nready = popc64(__ballot(!walking && phase != P_DONE));
+        // (every lane is alive here, so masks of single comparisons can be combined as scalars; a ballot of `a && b` would
+        // first write the bool to a register and compare it again)
+        const unsigned long long walk_mask = __ballot(walking), active_mask = ~walk_mask & __ballot(phase != P_DONE);
+        const int nwalk = popc64(walk_mask);
+        const int nready = popc64(active_mask);
         if (nready + nwalk == 0) break;
         if (guard >= CRT_GUARD_PASSES) { guard_tripped = true; break; }
         if (nready >= threshold || nwalk == 0) {
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
             // Atomics on one address are served ~5 ns apart device-wide and every wave waits its turn (measured: 2 M per
             // frame cost 10 ms), hence blocks, and several counters.
             const bool fetching = active && phase == P_FETCH;
-            const unsigned long long fm = __ballot(fetching);
+            const unsigned long long fm = active_mask & __ballot(phase == P_FETCH);
             if (fm) {
                 const RenderArgs rak = load_kernel_arg<RenderArgs>(offsetof(KernelArgsLayout, ra)); // the frame geometry is only needed here
                 const uint32_t chunk_spp = rak.spp >> rak.chunk_shift, chunk_mask = rak.chunks - 1u;
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                 bool in_lds = false;
                 int n_lds = 0;
                 if constexpr (NC > 0) {
-                    in_lds = inner && tv.cur < node_src.ncached;
+                    in_lds = (unsigned)tv.cur < (unsigned)node_src.ncached; // leaf references and the end-of-walk value are beyond it as unsigned
                     n_lds = popc64(__ballot(in_lds));
                 }
                 if (NC > 0 && n_lds * CRT_LDS_VOTE_DEN >= n_inner * CRT_LDS_VOTE_NUM && n_lds >= n_leaf) {
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                     if (in_lds) trav_inner_from(top, tv, stack, cnt);
 #pragma unroll
                     for (int k = 1; k < CRT_LDS_STEPS_PER_VOTE; k++) {
-                        const bool again = in_lds && is_inner(tv.cur) && tv.cur < node_src.ncached;
+                        const bool again = in_lds && (unsigned)tv.cur < (unsigned)node_src.ncached;
                         if constexpr (COUNT_WORK) { const int na = popc64(__ballot(again)); if (lane == 0) { wc[4]++; wc[5] += na; } }
                         if (again) trav_inner_from(top, tv, stack, cnt);
                     }

@@ -105,6 +105,30 @@ struct Trav {
     int cur;      // current ref (node >= 0, leaf < 0) or CRT_BVH_NONE when the walk is over
 };
 
+// min(a, b) for operands that are never NaN.  In IEEE mode the compiler has to quiet a possible signalling NaN before every
+// v_min / v_max whose operand it cannot trace to an arithmetic result (`v_max_f32 x, x, x`): one instruction per node step
+// for the walk's far limit, which lives in a register across the whole state machine.  (Pruning arithmetic only.)
+CRT_HD float min_no_nan(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return __builtin_fminf(a, b);
+#endif
+}
+
+// x limited to [-1e30, 1e30] (x is never NaN): one v_med3_f32
+CRT_HD float clamp_1e30(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(x, -1e30f, 1e30f);
+#else
+    return __builtin_fminf(__builtin_fmaxf(x, -1e30f), 1e30f);
+#endif
+}
+
 CRT_HD float fast_rcp(float x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -167,10 +191,7 @@ CRT_HD void trav_root(const SceneView &sc, f3 o, f3 d, const Search &s, float t_
     // slab arithmetic for pruning: idir finite, origin re-based to the root box entry so that rounding stays
     // small against the box margin wherever the ray starts.
     // (pruning only, so the 1-ulp hardware reciprocal is enough; it never touches a result)
-    f3 idir = mk3(fast_rcp(d.x), fast_rcp(d.y), fast_rcp(d.z));
-    if (!(__builtin_fabsf(idir.x) <= 1e30f)) idir.x = __builtin_copysignf(1e30f, d.x);
-    if (!(__builtin_fabsf(idir.y) <= 1e30f)) idir.y = __builtin_copysignf(1e30f, d.y);
-    if (!(__builtin_fabsf(idir.z) <= 1e30f)) idir.z = __builtin_copysignf(1e30f, d.z);
+    const f3 idir = mk3(clamp_1e30(fast_rcp(d.x)), clamp_1e30(fast_rcp(d.y)), clamp_1e30(fast_rcp(d.z))); // 1 / +-0 = +-inf -> +-1e30
     const float ax = (sc.root_min.x - o.x) * idir.x, bx = (sc.root_max.x - o.x) * idir.x;
     const float ay = (sc.root_min.y - o.y) * idir.y, by = (sc.root_max.y - o.y) * idir.y;
     const float az = (sc.root_min.z - o.z) * idir.z, bz = (sc.root_max.z - o.z) * idir.z;
@@ -178,7 +199,7 @@ CRT_HD void trav_root(const SceneView &sc, f3 o, f3 d, const Search &s, float t_
     const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
     const float bound = ((MODE == MODE_CLOSEST) ? s.t : t_hi) + CRT_TIE_WINDOW;
     if (!(tn <= tf && tf >= 0.0f && tn <= bound)) return;
-    tv.shift = __builtin_fmaxf(tn, 0.0f);
+    tv.shift = __builtin_fmaxf(tn, 0.0f); // (the same trick here, min_no_nan's counterpart, measured 2.8 % SLOWER: the asm pins the schedule of the shade phase)
     const f3 ob = axpy(tv.shift, d, o);
     tv.idir = idir;
     tv.ood = mk3(ob.x * idir.x, ob.y * idir.y, ob.z * idir.z);
@@ -223,11 +244,11 @@ CRT_HD void trav_inner_from(const Nodes &src, Trav &tv, Stack &stack, Counters &
     const float tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a0x, b0x), __builtin_fminf(a0y, b0y)),
                                       __builtin_fmaxf(__builtin_fminf(a0z, b0z), lo));
     const float tf0 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a0x, b0x), __builtin_fmaxf(a0y, b0y)),
-                                      __builtin_fminf(__builtin_fmaxf(a0z, b0z), hi));
+                                      min_no_nan(__builtin_fmaxf(a0z, b0z), hi));
     const float tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(a1x, b1x), __builtin_fminf(a1y, b1y)),
                                       __builtin_fmaxf(__builtin_fminf(a1z, b1z), lo));
     const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a1x, b1x), __builtin_fmaxf(a1y, b1y)),
-                                      __builtin_fminf(__builtin_fmaxf(a1z, b1z), hi));
+                                      min_no_nan(__builtin_fmaxf(a1z, b1z), hi));
     const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
     const int r0 = f2i(n0.w), r1 = f2i(n1.w);
     // branch-free selection: near child next, far child pushed; one hit: that child; none: pop
