@@ -554,6 +554,7 @@ static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
         std::nth_element(radii.begin(), radii.begin() + (long)(radii.size() / 2), radii.end());
         big = 16.0f * radii[radii.size() / 2];
     }
+    for (HostSphere &sp : s->spheres) sp.inv_radius = reciprocal_if_exact(sp.radius); // for the hit normal's (p - c) / radius (sphere.h:45)
     for (size_t k = 0; k < s->spheres.size(); k++) {
         const HostSphere &sp = s->spheres[k];
         const uint32_t id = (uint32_t)(s->tris.size() + k), rank = s->rank[s->tris.size() + k];
@@ -562,7 +563,7 @@ static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
         } else {
             Sphere o;
             o.cx = sp.center.x; o.cy = sp.center.y; o.cz = sp.center.z; o.radius = sp.radius;
-            o.id = (int)id; o.rank = (int)rank; o.mat = sp.material; o.pad = 0;
+            o.id = (int)id; o.rank = (int)rank; o.mat = sp.material; o.inv_radius = sp.inv_radius;
             flat.push_back(o);
         }
     }

@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <numeric>
 
 namespace crt {
@@ -151,7 +153,7 @@ struct Builder {
             if (refs[i].tri >= tris.size()) { // sphere slot
                 const BvhSphere &sp = spheres[refs[i].tri - tris.size()];
                 q4 a, b, c;
-                a.x = sp.s.center.x; a.y = sp.s.center.y; a.z = sp.s.center.z; b.x = sp.s.radius; b.y = b.z = 0.0f; c.x = c.y = c.z = 0.0f;
+                a.x = sp.s.center.x; a.y = sp.s.center.y; a.z = sp.s.center.z; b.x = sp.s.radius; b.y = sp.s.inv_radius; b.z = 0.0f; c.x = c.y = c.z = 0.0f;
                 const int id = (int)sp.id, rk = (int)(sp.rank | CRT_SPHERE_SLOT), mat = sp.s.material;
                 std::memcpy(&a.w, &id, 4); std::memcpy(&b.w, &rk, 4); std::memcpy(&c.w, &mat, 4);
                 out.tris.push_back(a); out.tris.push_back(b); out.tris.push_back(c);
@@ -337,6 +339,34 @@ void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t
     out.root_ref = b.build(0, b.refs.size(), CRT_STACK_DEPTH, 1, out.root_box);
 
     renumber_breadth_first(out.nodes, out.root_ref);
+}
+
+float reciprocal_if_exact(float s)
+{
+    if (!(s >= 0x1p-20f && s <= 0x1p+20f)) return 0.0f;
+    static std::mutex mutex;
+    static std::map<uint32_t, float> known;
+    uint32_t key;
+    std::memcpy(&key, &s, 4);
+    {
+        std::lock_guard<std::mutex> lock(mutex);
+        auto it = known.find(key);
+        if (it != known.end()) return it->second;
+        if (known.size() >= 256) return 0.0f; // a scene with that many different radii: the rest divide the ordinary way
+    }
+    const float y = 1.0f / s;
+    bool exact = true;
+    for (uint32_t m = 0; m < (1u << 23) && exact; m++) { // every significand at one exponent; both signs behave alike
+        const uint32_t bits = 0x40000000u | m;
+        float a;
+        std::memcpy(&a, &bits, 4);
+        const float q = a * y, got = __builtin_fmaf(__builtin_fmaf(-s, q, a), y, q), want = a / s;
+        exact = std::memcmp(&got, &want, 4) == 0;
+    }
+    const float result = exact ? y : 0.0f;
+    std::lock_guard<std::mutex> lock(mutex);
+    known[key] = result;
+    return result;
 }
 
 } // namespace crt

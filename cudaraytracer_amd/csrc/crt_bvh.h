@@ -11,7 +11,11 @@
 namespace crt {
 
 struct HostTriangle { f3 a, b, c; int material; };
-struct HostSphere { f3 center; float radius_arg; float radius; int material; }; // radius = max(0, radius_arg) (sphere.h:11)
+struct HostSphere { f3 center; float radius_arg; float radius; int material; float inv_radius = 0.0f; }; // radius = max(0, radius_arg) (sphere.h:11); inv_radius: reciprocal_if_exact(radius), set at commit
+
+// RN(1 / s) if crt_core.h's div3_exact with it equals IEEE division for every numerator significand (checked exhaustively,
+// 2^23 cases, ~10 ms; results are kept per divisor), else 0.  Divisors outside [2^-20, 2^20] get 0.
+float reciprocal_if_exact(float s);
 
 struct Box { f3 mn, mx; };
 

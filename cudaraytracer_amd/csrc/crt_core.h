@@ -34,6 +34,23 @@ CRT_HD f3 div3(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
 CRT_HD float fma1(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 // a + s*b, one fma per component
 CRT_HD f3 axpy(float s, f3 b, f3 a) { return mk3(fma1(s, b.x, a.x), fma1(s, b.y, a.y), fma1(s, b.z, a.z)); }
+
+// a / s for a divisor whose correctly rounded reciprocal y = RN(1 / s) came with the scene: q = a * y, then one correction by
+// the exact remainder, q + fma(-s, q, a) * y -- three instructions per component where the IEEE division sequence takes
+// thirteen.  That this IS the correctly rounded quotient is not taken on trust: for every divisor that gets a reciprocal,
+// commit has compared it with a / s for all 2^23 significands of a (crt_bvh.cpp: reciprocal_if_exact; scaling a by a
+// power of two scales every intermediate exactly as long as nothing leaves the normal range, hence the range check
+// here and the divisor range there).  y == 0: no reciprocal, plain division.
+CRT_HD f3 div3_exact(f3 a, float s, float y)
+{
+    const float lo = __builtin_fminf(__builtin_fminf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), __builtin_fabsf(a.z));
+    if (y != 0.0f && lo >= 0x1p-60f && hi <= 0x1p+60f) {
+        const float qx = a.x * y, qy = a.y * y, qz = a.z * y;
+        return mk3(fma1(fma1(-s, qx, a.x), y, qx), fma1(fma1(-s, qy, a.y), y, qy), fma1(fma1(-s, qz, a.z), y, qz));
+    }
+    return div3(a, s);
+}
 // glm::dot order (x*x' + y*y') + z*z', contracted left to right
 CRT_HD float dot(f3 a, f3 b) { return fma1(a.z, b.z, fma1(a.y, b.y, a.x * b.x)); }
 // glm::cross, each difference of products as fma(p, q, -(r*s))
@@ -185,7 +202,7 @@ CRT_HD bool sphere_accepts(float t, float closest) { return t <= closest; }
 // ---------------------------------------------------------------------------------------------------------
 struct Material { int type; float r, g, b; float param; int tex; int pad0, pad1; };               // 32 B
 struct Texture { int type; float ar, ag, ab; float br, bg, bb; float inv_scale; };                // 32 B
-struct Sphere { float cx, cy, cz, radius; int id; int rank; int mat; int pad; };                  // 32 B
+struct Sphere { float cx, cy, cz, radius; int id; int rank; int mat; float inv_radius; };         // 32 B; inv_radius: RN(1 / radius) if commit proved div3_exact with it, else 0
 // Device record of a material joined with its texture (48 B, built at commit): one fetch per shaded hit instead
 // of material -> texture.  Colour a/b: the texture of a Lambertian / DiffuseLight (texture.h), the albedo of a Metal
 // (material.h:48) and (1,1,1) for a Dielectric (material.h:66), so that every material's colour is texture_value().

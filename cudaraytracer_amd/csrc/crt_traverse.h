@@ -401,12 +401,12 @@ CRT_HD Surface surface_at(const SceneView &sc, int code, f3 o, f3 d, float t)
     } else if (SPHERE_SLOTS && (code & CRT_SPHERE_SLOT)) {
         const size_t k = 3 * (size_t)(code & ~CRT_SPHERE_SLOT);
         const q4 ta = load_global(sc.tris, k), tb = load_global(sc.tris, k + 1);
-        const f3 outward = div3(r.point - mk3(ta.x, ta.y, ta.z), tb.x); // sphere.h:45
+        const f3 outward = div3_exact(r.point - mk3(ta.x, ta.y, ta.z), tb.x, tb.y); // sphere.h:45
         r.normal = face_normal(d, outward, r.front_face);
         r.prim = f2i(ta.w);
     } else {
         const Sphere sp = load_global(sc.spheres, (uint32_t)code - sc.ntris);
-        const f3 outward = div3(r.point - mk3(sp.cx, sp.cy, sp.cz), sp.radius);
+        const f3 outward = div3_exact(r.point - mk3(sp.cx, sp.cy, sp.cz), sp.radius, sp.inv_radius);
         r.normal = face_normal(d, outward, r.front_face);
         r.prim = sp.id;
     }

@@ -255,3 +255,15 @@ extern "C" int hostsim_entry_point_study(const crt_scene *s, const crt_camera *c
     }
     return CRT_OK;
 }
+
+// crt_core.h: div3_exact with the reciprocal commit would store for divisor `s` (crt_bvh.cpp: reciprocal_if_exact), n
+// numerator triples; *y_out = that reciprocal (0: the divisor gets none and div3_exact divides the ordinary way)
+extern "C" void hostsim_div3_exact(float s, const float *a, uint32_t n, float *q, float *y_out)
+{
+    const float y = crt::reciprocal_if_exact(s);
+    *y_out = y;
+    for (uint32_t k = 0; k < n; k++) {
+        const crt::f3 r = crt::div3_exact(crt::mk3(a[3 * k], a[3 * k + 1], a[3 * k + 2]), s, y);
+        q[3 * k] = r.x; q[3 * k + 1] = r.y; q[3 * k + 2] = r.z;
+    }
+}

@@ -288,3 +288,31 @@ def test_tie_window_follows_a_creeping_chain(hostsim, oracle, capi):
         assert prim == ref_prim and t == ref_t and took, (o, d, prim, ref_prim)
         far_wins += ref_prim >= 13                                                             # > 1.1e-6 behind the nearest triangle
     assert far_wins > 50
+
+
+def test_division_by_a_sphere_radius_is_ieee_division(hostsim):
+    """The hit normal (p - c) / radius (sphere.h:45) multiplies by a reciprocal that commit has proved exact for that radius
+    (all 2^23 numerator significands): the quotients must be numpy's float32 divisions bit for bit, for ordinary numerators
+    and for the ones the fast path hands to the plain division (zeros, denormals, tiny, huge, infinities), and radii outside
+    [2^-20, 2^20] get no reciprocal at all."""
+    import ctypes as C
+    L = hostsim.L
+    L.hostsim_div3_exact.argtypes = [C.c_float, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(C.c_float)]
+    L.hostsim_div3_exact.restype = None
+    rng = np.random.default_rng(7)
+    n = 30000
+    bits = rng.integers(0, 2**32, size=3 * n, dtype=np.uint64).astype(np.uint32)
+    a = bits.view(np.float32).copy()
+    a[np.isnan(a)] = np.float32(1.5)
+    a[:12] = np.array([0.0, -0.0, 1e-45, -1e-40, 1e-30, 3e38, np.inf, -np.inf, 1.0, 2.0, 1000.0, 2.0 ** -60], dtype=np.float32)
+    mid = (rng.standard_normal(3 * n) * 1000).astype(np.float32)        # what hit points on a sphere look like
+    for radius, has_reciprocal in ((1000.0, True), (2.0, True), (0.2, True), (1.0, True), (3.7, True), (1.9999999, True), (1e-7, False), (3e6, False)):
+        r32 = np.float32(radius)
+        for numer in (a, mid):
+            q = np.empty_like(numer)
+            y = C.c_float()
+            L.hostsim_div3_exact(float(r32), numer.ctypes.data, n, q.ctypes.data, C.byref(y))
+            assert (y.value != 0.0) == has_reciprocal and (not has_reciprocal or np.float32(y.value) == np.float32(1.0) / r32)
+            with np.errstate(all="ignore"):
+                want = numer / r32
+            assert np.array_equal(q.view(np.uint32), want.view(np.uint32)), radius
