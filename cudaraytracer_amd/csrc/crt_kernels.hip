@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
             if (active && phase == P_HIT) {
                 float t = 0.0f;
                 int mat = 0;
-                const int code = resolve_hit(sck, p.o, p.d, tmin, FLT_MAX, hit, t, mat, stack, cnt);
+                const int code = resolve_hit_in_place(sck, p.o, p.d, tmin, FLT_MAX, hit, t, mat, stack, cnt, tv); // (hit and tv are dead here)
                 if (code < 0) { // camera.h:68-71
                     p.color = mk3(fma1(p.attenuation.x, cam.background.x, p.color.x), fma1(p.attenuation.y, cam.background.y, p.color.y),
                                   fma1(p.attenuation.z, cam.background.z, p.color.z));

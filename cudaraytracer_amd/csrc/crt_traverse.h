@@ -299,14 +299,20 @@ CRT_HD void trav_leaf(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, in
 
 // One whole walk over spheres + BVH.
 template <int MODE, class Stack, class Counters>
-CRT_HD void walk(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Stack &stack, Counters &cnt)
+CRT_HD void walk(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Stack &stack, Counters &cnt, Trav &tv)
 {
-    Trav tv;
     trav_begin<MODE>(sc, o, d, tmin, s, after_rank, t_hi, tv, stack, cnt);
     while (tv.cur != CRT_BVH_NONE) {
         while (is_inner(tv.cur)) trav_inner(sc, tv, stack, cnt);
         if (tv.cur < 0) trav_leaf<MODE>(sc, o, d, tmin, s, after_rank, t_hi, tv, stack, cnt);
     }
+}
+
+template <int MODE, class Stack, class Counters>
+CRT_HD void walk(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Stack &stack, Counters &cnt)
+{
+    Trav tv;
+    walk<MODE>(sc, o, d, tmin, s, after_rank, t_hi, stack, cnt, tv);
 }
 
 // The fold in reference leaf order over the candidates with t <= t_min + window: one MODE_NEXT_RANK walk per candidate,
@@ -316,8 +322,13 @@ CRT_HD void walk(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int aft
 // end of the window and beyond; `reach` is the largest t the reference could still have accepted after m, and when it lies
 // outside the window the fold is done again over a window that contains it.  (Nearly always one pass; a second one needs
 // >= 9 successively accepted candidates behind the minimum.)
+// `n` and `tv` are working storage (the render kernel hands in its lane's own search and walk state, which are dead while a
+// hit is being resolved: the fold then needs no registers beyond the shade phase's and nothing is parked in scratch
+// memory -- whose reload, a vector memory load, put an s_waitcnt vmcnt(0) on the COMMON path behind the pixel store);
+// tv.cur is CRT_BVH_NONE again on return.
 template <class Stack, class Counters>
-CRT_HD int refold(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float t_min, float &t_hit, int &mat_hit, Stack &stack, Counters &cnt)
+CRT_HD int refold(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float t_min, float &t_hit, int &mat_hit, Stack &stack, Counters &cnt, Search &n,
+                  Trav &tv)
 {
     float t_hi = t_min + CRT_TIE_WINDOW;
     float closest = tmax;
@@ -329,9 +340,8 @@ CRT_HD int refold(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float
         bool seen_min = false;
         float reach = -FLT_MAX;
         for (;;) {
-            Search n;
             n.t = 0.0f; n.code = -1; n.mat = 0; n.rank = 0x7FFFFFFF; n.near_tie = false;
-            walk<MODE_NEXT_RANK>(sc, o, d, tmin, n, after, t_hi, stack, cnt);
+            walk<MODE_NEXT_RANK>(sc, o, d, tmin, n, after, t_hi, stack, cnt, tv);
             if (n.code < 0) break;
             const bool is_tri = (uint32_t)n.code < sc.ntris;
             seen_min = seen_min || n.t == t_min;
@@ -347,6 +357,13 @@ CRT_HD int refold(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float
     t_hit = closest;
     return win;
 }
+template <class Stack, class Counters>
+CRT_HD int refold(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float t_min, float &t_hit, int &mat_hit, Stack &stack, Counters &cnt)
+{
+    Search n;
+    Trav tv;
+    return refold(sc, o, d, tmin, tmax, t_min, t_hit, mat_hit, stack, cnt, n, tv);
+}
 
 // After a MODE_CLOSEST walk: the reference's winner.  Fast path when no two candidates came within the tie
 // window; otherwise the fold in reference leaf order.
@@ -358,6 +375,18 @@ CRT_HD int resolve_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, 
     if (!s.near_tie) { t_hit = s.t; mat_hit = s.mat; return s.t <= tmax ? s.code : -1; }
     cnt.refold();
     return refold(sc, o, d, tmin, tmax, s.t, t_hit, mat_hit, stack, cnt);
+}
+// The same for a caller whose search `s` and walk state `tv` are free to be used as the fold's working storage (see refold):
+// `s` is consumed, tv.cur must be and stays CRT_BVH_NONE.
+template <class Stack, class Counters>
+CRT_HD int resolve_hit_in_place(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, Search &s, float &t_hit, int &mat_hit, Stack &stack, Counters &cnt,
+                                Trav &tv)
+{
+    if (s.code < 0) return -1;
+    if (!s.near_tie) { t_hit = s.t; mat_hit = s.mat; return s.t <= tmax ? s.code : -1; }
+    cnt.refold();
+    const float t_min = s.t;
+    return refold(sc, o, d, tmin, tmax, t_min, t_hit, mat_hit, stack, cnt, s, tv);
 }
 
 // world->hit(ray, Interval(tmin, FLT_MAX), rec) (camera.h:68 -> hittable_list.h:17-63): returns the winning
