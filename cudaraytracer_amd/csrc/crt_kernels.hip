@@ -168,8 +168,65 @@ struct LdsNodes { // the LDS copy only (the caller has checked cur < ncached)
     {
         lds_q4_ptr n = lds + 4u * (uint32_t)cur;
         n0 = to_q4(n[0]); n1 = to_q4(n[1]); n2 = to_q4(n[2]); n3 = to_q4(n[3]);
+#ifdef CRT_EXTRA_MINMAX
+        { // cost probe: CRT_EXTRA_MINMAX independent v_min_f32 per LDS node step (results unused)
+            float a = n0.x, b = n1.x;
+#pragma unroll
+            for (int k = 0; k < CRT_EXTRA_MINMAX; k++) asm volatile("v_min_f32_e32 %0, %1, %2" : "=v"(a) : "v"(a), "v"(b));
+        }
+#endif
     }
 };
+
+// The LDS node step with the slab planes picked by the signs of the ray direction instead of by min / max.  A ray whose
+// direction is positive along x enters every box through its min.x plane and leaves through max.x (t = plane * idir - ood is
+// monotone in the plane, roundings included), so near and far planes are known per ray and need not be found per node: per
+// child max3 + max for the entry time and min3 + min for the exit time, 8 instructions of the 4-cycle class per step where the
+// pairwise form takes 20.  The price is per-lane addressing -- twelve 4-byte LDS reads at `node + 16 * (sign bit)` instead of
+// four 16-byte ones, and six address additions -- which only the LDS copy can afford (from device memory every load costs
+// the address unit 16 cycles whatever its width).  Same boxes, same decisions as trav_inner_from, bit for bit.
+#ifndef CRT_SORTED_LDS_STEP
+#define CRT_SORTED_LDS_STEP 1
+#endif
+
+typedef __attribute__((address_space(3))) const float *lds_f32_ptr;
+typedef __attribute__((address_space(3))) const unsigned char *lds_u8_ptr;
+struct SignOffsets { uint32_t nx, ny, nz, fx, fy, fz; }; // byte offsets of the near / far plane rows within a node: 0 (min row) or 16 (max row)
+__device__ __forceinline__ SignOffsets sign_offsets(const Trav &tv)
+{
+    SignOffsets o;
+    o.nx = ((uint32_t)f2i(tv.idir.x) >> 31) << 4; o.ny = ((uint32_t)f2i(tv.idir.y) >> 31) << 4; o.nz = ((uint32_t)f2i(tv.idir.z) >> 31) << 4;
+    o.fx = o.nx ^ 16u; o.fy = o.ny ^ 16u; o.fz = o.nz ^ 16u;
+    return o;
+}
+template <class Stack, class Counters>
+__device__ __forceinline__ void trav_inner_lds_sorted(lds_q4_ptr nodes, const SignOffsets &so, Trav &tv, Stack &stack, Counters &cnt)
+{
+    const lds_u8_ptr node = (lds_u8_ptr)nodes + 64u * (uint32_t)tv.cur; // (a 68-byte stride that spreads the nodes over all LDS banks: no change)
+    const lds_f32_ptr nx = (lds_f32_ptr)(node + so.nx), ny = (lds_f32_ptr)(node + so.ny), nz = (lds_f32_ptr)(node + so.nz);
+    const lds_f32_ptr fx = (lds_f32_ptr)(node + so.fx), fy = (lds_f32_ptr)(node + so.fy), fz = (lds_f32_ptr)(node + so.fz);
+    const lds_f32_ptr row = (lds_f32_ptr)node;
+    // child 0: rows at +0 (min) and +16 (max); child 1: +32 and +48, i.e. 8 floats further
+    const float n0x = nx[0], n0y = ny[1], n0z = nz[2], f0x = fx[0], f0y = fy[1], f0z = fz[2];
+    const float n1x = nx[8], n1y = ny[9], n1z = nz[10], f1x = fx[8], f1y = fy[9], f1z = fz[10];
+    const int r0 = f2i(row[3]), r1 = f2i(row[7]);
+    const int below = stack.peek();
+    cnt.node();
+    const f3 idir = tv.idir, ood = tv.ood;
+    const float lo = -tv.shift, hi = tv.hi;
+    const float tn0 = __builtin_fmaxf(__builtin_fmaxf(fma1(n0x, idir.x, -ood.x), fma1(n0y, idir.y, -ood.y)), __builtin_fmaxf(fma1(n0z, idir.z, -ood.z), lo));
+    const float tf0 = __builtin_fminf(__builtin_fminf(fma1(f0x, idir.x, -ood.x), fma1(f0y, idir.y, -ood.y)), min_no_nan(fma1(f0z, idir.z, -ood.z), hi));
+    const float tn1 = __builtin_fmaxf(__builtin_fmaxf(fma1(n1x, idir.x, -ood.x), fma1(n1y, idir.y, -ood.y)), __builtin_fmaxf(fma1(n1z, idir.z, -ood.z), lo));
+    const float tf1 = __builtin_fminf(__builtin_fminf(fma1(f1x, idir.x, -ood.x), fma1(f1y, idir.y, -ood.y)), min_no_nan(fma1(f1z, idir.z, -ood.z), hi));
+    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
+    const bool swap = tn1 < tn0;
+    const int near_ref = swap ? r1 : r0, far_ref = swap ? r0 : r1;
+    const bool both = h0 && h1, none = !h0 && !h1;
+    stack.push_if(far_ref, both);
+    const int next = both ? near_ref : (h0 ? r0 : r1);
+    stack.pop_if(none);
+    tv.cur = none ? below : next;
+}
 
 // Section clock of the instrumented kernel (CRT_COUNT_WORK): shader-clock ticks a wave spends in each part of the loop
 template <bool ON>
@@ -505,6 +562,16 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                 }
                 if (NC > 0 && n_lds * CRT_LDS_VOTE_DEN >= n_inner * CRT_LDS_VOTE_NUM && n_lds >= n_leaf) {
                     if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_lds; } }
+#if CRT_SORTED_LDS_STEP
+                    const SignOffsets so = sign_offsets(tv);
+                    if (in_lds) trav_inner_lds_sorted(node_src.lds, so, tv, stack, cnt);
+#pragma unroll
+                    for (int k = 1; k < CRT_LDS_STEPS_PER_VOTE; k++) {
+                        const bool again = in_lds && (unsigned)tv.cur < (unsigned)node_src.ncached;
+                        if constexpr (COUNT_WORK) { const int na = popc64(__ballot(again)); if (lane == 0) { wc[4]++; wc[5] += na; } }
+                        if (again) trav_inner_lds_sorted(node_src.lds, so, tv, stack, cnt);
+                    }
+#else
                     LdsNodes top;
                     top.lds = node_src.lds;
                     if (in_lds) trav_inner_from(top, tv, stack, cnt);
@@ -514,6 +581,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                         if constexpr (COUNT_WORK) { const int na = popc64(__ballot(again)); if (lane == 0) { wc[4]++; wc[5] += na; } }
                         if (again) trav_inner_from(top, tv, stack, cnt);
                     }
+#endif
                     CRT_LAP(clk, 7);
                 } else if (n_inner >= n_leaf) {
                     // (all lanes at a node take part: the loads cost the address unit the same whatever the number of lanes)
