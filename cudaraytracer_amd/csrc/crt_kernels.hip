@@ -4,7 +4,7 @@
 // samples -- taken in blocks of 2^fetch_shift units (RenderArgs, chosen by launch_render) from 64 striped block counters (units are numbered in 8x8-tile
 // order: the reference's block shape, kernel.cu:50-51, renderer.h:51-52); a unit's samples are summed in the lane in
 // sample order (renderer.h:28-32), so the float sum is the reference's whatever the partition.  Waves run four to a
-// workgroup and share an LDS copy of the top of the tree (CRT_NODE_CACHE_NODES = 192 nodes for trees up to 16 deep: 4 x
+// workgroup and share an LDS copy of the top of the tree (CRT_NODE_CACHE_NODES = 208 nodes for trees up to 16 deep: 4 x
 // 4.6 KB of stack + 12 KB of nodes = 30 KB, five workgroups = 20 waves per CU; 64 nodes for trees up to 24 deep), or one
 // to a workgroup without it.  The traversal stack is an LDS column per lane (stack[level][lane]: bank = lane, conflict
 // free).
@@ -282,7 +282,7 @@ static_assert(CRT_WORK_STRIPES == 64u, "the order in which a wave visits the blo
 #define CRT_NODE_STEPS_PER_VOTE 2
 #endif
 #ifndef CRT_NODE_CACHE_NODES
-#define CRT_NODE_CACHE_NODES 192 // 4 waves x 4.6 KB of stack + 12 KB of nodes = 30 KB per workgroup: five per CU = the same 20 waves
+#define CRT_NODE_CACHE_NODES 208 // 4 waves x 4.5 KB of stack + 13 KB of nodes = 31 KB per workgroup: five per CU = the same 20 waves (160 / 192 / 208 nodes: 9.00 / 8.98 / 8.94 ms; 220 leave room for four workgroups only: 10.1)
 #endif
 #ifndef CRT_LDS_VOTE_NUM
 #define CRT_LDS_VOTE_NUM 3 // an LDS-only node step when at least NUM/DEN of the lanes at a node are at a cached node
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
     // W waves per workgroup, each on its own; with NC > 0 they share an LDS copy of the first NC nodes (breadth-first
     // numbering: the top of the tree).  The kernel is limited by the CU's address unit as much as by VALU issue (one more
     // dwordx4 load per node step costs 13 % of the frame), and about 70 % of the node visits of the headline scene go to the
-    // first 192 nodes: those become ds_read_b128.  W = 4, NC = 192, SD = 16: 4 x 4.6 KB of stack + 12 KB of nodes = 30 KB,
+    // first ~200 nodes: those are read from LDS.  W = 4, NC = 208, SD = 16: 4 x 4.5 KB of stack + 13 KB of nodes = 31 KB,
     // five workgroups per CU = the same 20 waves as with one wave per workgroup.
     __shared__ int lds_stack_all[W][(SD + 2) * 64]; // SD = 16 when the BVH is at most 16 levels deep
     __shared__ v4f lds_nodes[NC > 0 ? 4 * NC : 1];
