@@ -218,14 +218,7 @@ __device__ __forceinline__ void trav_inner_lds_sorted(lds_q4_ptr nodes, const Si
     const float tf0 = __builtin_fminf(__builtin_fminf(fma1(f0x, idir.x, -ood.x), fma1(f0y, idir.y, -ood.y)), min_no_nan(fma1(f0z, idir.z, -ood.z), hi));
     const float tn1 = __builtin_fmaxf(__builtin_fmaxf(fma1(n1x, idir.x, -ood.x), fma1(n1y, idir.y, -ood.y)), __builtin_fmaxf(fma1(n1z, idir.z, -ood.z), lo));
     const float tf1 = __builtin_fminf(__builtin_fminf(fma1(f1x, idir.x, -ood.x), fma1(f1y, idir.y, -ood.y)), min_no_nan(fma1(f1z, idir.z, -ood.z), hi));
-    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-    const bool swap = tn1 < tn0;
-    const int near_ref = swap ? r1 : r0, far_ref = swap ? r0 : r1;
-    const bool both = h0 && h1, none = !h0 && !h1;
-    stack.push_if(far_ref, both);
-    const int next = both ? near_ref : (h0 ? r0 : r1);
-    stack.pop_if(none);
-    tv.cur = none ? below : next;
+    trav_descend(tn0, tf0, tn1, tf1, r0, r1, below, tv, stack);
 }
 
 // Section clock of the instrumented kernel (CRT_COUNT_WORK): shader-clock ticks a wave spends in each part of the loop

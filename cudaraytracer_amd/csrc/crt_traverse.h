@@ -225,6 +225,31 @@ struct GlobalNodes {
     }
 };
 
+// The end of a node step, branch-free: entry / exit times of the two child boxes -> near child next and far child pushed
+// (both hit), the one child that was hit, or a pop (`below` = what a pop returns, read ahead by the caller).  The child that
+// is not taken is stored to the stack top unconditionally: when nothing is pushed the store lands on the spare level and its
+// value does not matter, so "next" and "stored" are two selects on ONE mask.  On the device the three comparisons are
+// combined as 64-bit scalar masks (s_and / s_or / s_orn2): written as bool expressions the compiler evaluates `!(a <= b)`
+// with a second compare each (NaN-safe, but one more instruction of the 4-cycle class per negation).
+template <class Stack>
+CRT_HD void trav_descend(float tn0, float tf0, float tn1, float tf1, int r0, int r1, int below, Trav &tv, Stack &stack)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long m0 = __builtin_amdgcn_ballot_w64(tn0 <= tf0), m1 = __builtin_amdgcn_ballot_w64(tn1 <= tf1);
+    const unsigned long long msw = __builtin_amdgcn_ballot_w64(tn1 < tn0);
+    const bool both = __builtin_amdgcn_inverse_ballot_w64(m0 & m1), none = __builtin_amdgcn_inverse_ballot_w64(~(m0 | m1));
+    const bool take1 = __builtin_amdgcn_inverse_ballot_w64(~m0 | (m1 & msw));
+#else
+    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1, swap = tn1 < tn0;
+    const bool both = h0 && h1, none = !h0 && !h1;
+    const bool take1 = !h0 || (h1 && swap); // = both ? swap : !h0
+#endif
+    const int next = take1 ? r1 : r0, other = take1 ? r0 : r1;
+    stack.push_if(other, both);
+    stack.pop_if(none);
+    tv.cur = none ? below : next;
+}
+
 // One two-child node: both child boxes, near child next, far child pushed.  Requires is_inner(tv.cur).
 template <class Nodes, class Stack, class Counters>
 CRT_HD void trav_inner_from(const Nodes &src, Trav &tv, Stack &stack, Counters &cnt)
@@ -249,16 +274,7 @@ CRT_HD void trav_inner_from(const Nodes &src, Trav &tv, Stack &stack, Counters &
                                       __builtin_fmaxf(__builtin_fminf(a1z, b1z), lo));
     const float tf1 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(a1x, b1x), __builtin_fmaxf(a1y, b1y)),
                                       min_no_nan(__builtin_fmaxf(a1z, b1z), hi));
-    const bool h0 = tn0 <= tf0, h1 = tn1 <= tf1;
-    const int r0 = f2i(n0.w), r1 = f2i(n1.w);
-    // branch-free selection: near child next, far child pushed; one hit: that child; none: pop
-    const bool swap = tn1 < tn0;
-    const int near_ref = swap ? r1 : r0, far_ref = swap ? r0 : r1;
-    const bool both = h0 && h1, none = !h0 && !h1;
-    stack.push_if(far_ref, both);
-    const int next = both ? near_ref : (h0 ? r0 : r1);
-    stack.pop_if(none);
-    tv.cur = none ? below : next;
+    trav_descend(tn0, tf0, tn1, tf1, f2i(n0.w), f2i(n1.w), below, tv, stack);
 }
 
 template <class Stack, class Counters>
