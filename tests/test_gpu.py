@@ -199,6 +199,25 @@ def test_grid_scene_1m_triangles_sample(oracle, scenes, capi, node_cache):
     assert (ids >= 0).mean() > 0.5 and (ids < 999912).mean() > 0.2
 
 
+def test_frame_does_not_depend_on_the_schedule_knobs(monkeypatch, scenes, gpu_scenes):
+    """A lane's own operation order is the sequential one whatever the wave does around it, so the knobs that only move
+    work between lanes and waves -- units per trip to a block counter, the shade-phase threshold, waves per CU, interleaved
+    instead of banded block counters -- must leave every pixel, id and the ray count untouched (whole pixels and one
+    sample per unit, a ragged frame that ends in a partial block)."""
+    _, s = gpu_scenes("cats")
+    width, height, spp = 203, 117, 8
+    _, cam = scenes.make_camera(width)
+    for chunks in (1, spp):
+        ref = s.render(cam, width, height, spp, want_ids=True, sample_chunks=chunks)
+        for knob, values in (("CRT_FETCH_BLOCK", ("64", "256", "4096", "65536")), ("CRT_SCHED_THRESHOLD", ("1", "33", "64")),
+                             ("CRT_WAVES_PER_CU", ("4", "12")), ("CRT_STRIPE_BANDS", ("0",))):
+            for v in values:
+                monkeypatch.setenv(knob, v)
+                rgb, ids, st = s.render(cam, width, height, spp, want_ids=True, sample_chunks=chunks)
+                monkeypatch.delenv(knob, raising=False)
+                assert np.array_equal(rgb, ref[0]) and np.array_equal(ids, ref[1]) and st.rays == ref[2].rays, (chunks, knob, v)
+
+
 def test_context_pool_kernel_matches_default_kernel(monkeypatch, scenes, gpu_scenes):
     """CRT_KERNEL=1 selects the experimental LDS context-pool schedule (crt_kernels.hip: render_pool_kernel): other
     lanes render other pixels at other times, yet every pixel, id and the ray count must be identical."""
