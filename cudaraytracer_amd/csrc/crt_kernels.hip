@@ -4,7 +4,7 @@
 // samples -- taken in blocks of 2^fetch_shift units (RenderArgs, chosen by launch_render) from 64 striped block counters (units are numbered in 8x8-tile
 // order: the reference's block shape, kernel.cu:50-51, renderer.h:51-52); a unit's samples are summed in the lane in
 // sample order (renderer.h:28-32), so the float sum is the reference's whatever the partition.  Waves run four to a
-// workgroup and share an LDS copy of the top of the tree (CRT_NODE_CACHE_NODES = 208 nodes for trees up to 16 deep: 4 x
+// workgroup and share an LDS copy of the top of the tree (CRT_NODE_CACHE_NODES = 236 nodes for trees up to 16 deep: 4 x
 // 4.6 KB of stack + 12 KB of nodes = 30 KB, five workgroups = 20 waves per CU; 64 nodes for trees up to 24 deep), or one
 // to a workgroup without it.  The traversal stack is an LDS column per lane (stack[level][lane]: bank = lane, conflict
 // free).
@@ -185,31 +185,32 @@ struct LdsNodes { // the LDS copy only (the caller has checked cur < ncached)
 // pairwise form takes 20.  The price is per-lane addressing -- twelve 4-byte LDS reads at `node + 16 * (sign bit)` instead of
 // four 16-byte ones, and six address additions -- which only the LDS copy can afford (from device memory every load costs
 // the address unit 16 cycles whatever its width).  Same boxes, same decisions as trav_inner_from, bit for bit.
-#ifndef CRT_SORTED_LDS_STEP
-#define CRT_SORTED_LDS_STEP 1
-#endif
 
 typedef __attribute__((address_space(3))) const float *lds_f32_ptr;
 typedef __attribute__((address_space(3))) const unsigned char *lds_u8_ptr;
-struct SignOffsets { uint32_t nx, ny, nz, fx, fy, fz; }; // byte offsets of the near / far plane rows within a node: 0 (min row) or 16 (max row)
+// The LDS copy holds a node in 56 bytes, not 64 (the two unused words of the device record are dropped: 14 % more nodes in the
+// same LDS): [c0.min xyz][c0.max xyz][c1.min xyz][c1.max xyz][ref0 ref1].
+#define CRT_LDS_NODE_BYTES 56u
+#define CRT_LDS_NODE_WORDS 14u
+struct SignOffsets { uint32_t nx, ny, nz, fx, fy, fz; }; // byte offsets of the near / far plane rows within a node: 0 (min row) or 12 (max row)
 __device__ __forceinline__ SignOffsets sign_offsets(const Trav &tv)
 {
     SignOffsets o;
-    o.nx = ((uint32_t)f2i(tv.idir.x) >> 31) << 4; o.ny = ((uint32_t)f2i(tv.idir.y) >> 31) << 4; o.nz = ((uint32_t)f2i(tv.idir.z) >> 31) << 4;
-    o.fx = o.nx ^ 16u; o.fy = o.ny ^ 16u; o.fz = o.nz ^ 16u;
+    o.nx = ((uint32_t)(f2i(tv.idir.x) >> 31)) & 12u; o.ny = ((uint32_t)(f2i(tv.idir.y) >> 31)) & 12u; o.nz = ((uint32_t)(f2i(tv.idir.z) >> 31)) & 12u;
+    o.fx = o.nx ^ 12u; o.fy = o.ny ^ 12u; o.fz = o.nz ^ 12u;
     return o;
 }
 template <class Stack, class Counters>
 __device__ __forceinline__ void trav_inner_lds_sorted(lds_q4_ptr nodes, const SignOffsets &so, Trav &tv, Stack &stack, Counters &cnt)
 {
-    const lds_u8_ptr node = (lds_u8_ptr)nodes + 64u * (uint32_t)tv.cur; // (a 68-byte stride that spreads the nodes over all LDS banks: no change)
+    const lds_u8_ptr node = (lds_u8_ptr)nodes + CRT_LDS_NODE_BYTES * (uint32_t)tv.cur; // (a stride that spreads the nodes over all LDS banks, 68 bytes: no change)
     const lds_f32_ptr nx = (lds_f32_ptr)(node + so.nx), ny = (lds_f32_ptr)(node + so.ny), nz = (lds_f32_ptr)(node + so.nz);
     const lds_f32_ptr fx = (lds_f32_ptr)(node + so.fx), fy = (lds_f32_ptr)(node + so.fy), fz = (lds_f32_ptr)(node + so.fz);
     const lds_f32_ptr row = (lds_f32_ptr)node;
-    // child 0: rows at +0 (min) and +16 (max); child 1: +32 and +48, i.e. 8 floats further
+    // child 0: rows at +0 (min) and +12 (max); child 1: +24 and +36, i.e. 6 floats further; the references behind them
     const float n0x = nx[0], n0y = ny[1], n0z = nz[2], f0x = fx[0], f0y = fy[1], f0z = fz[2];
-    const float n1x = nx[8], n1y = ny[9], n1z = nz[10], f1x = fx[8], f1y = fy[9], f1z = fz[10];
-    const int r0 = f2i(row[3]), r1 = f2i(row[7]);
+    const float n1x = nx[6], n1y = ny[7], n1z = nz[8], f1x = fx[6], f1y = fy[7], f1z = fz[8];
+    const int r0 = f2i(row[12]), r1 = f2i(row[13]);
     const int below = stack.peek();
     cnt.node();
     const f3 idir = tv.idir, ood = tv.ood;
@@ -275,7 +276,7 @@ static_assert(CRT_WORK_STRIPES == 64u, "the order in which a wave visits the blo
 #define CRT_NODE_STEPS_PER_VOTE 2
 #endif
 #ifndef CRT_NODE_CACHE_NODES
-#define CRT_NODE_CACHE_NODES 208 // 4 waves x 4.5 KB of stack + 13 KB of nodes = 31 KB per workgroup: five per CU = the same 20 waves (160 / 192 / 208 nodes: 9.00 / 8.98 / 8.94 ms; 220 leave room for four workgroups only: 10.1)
+#define CRT_NODE_CACHE_NODES 236 // 4 waves x 4.5 KB of stack + 236 x 56 B of nodes = 31.6 KB per workgroup: five per CU = the same 20 waves (160 / 192 / 208 nodes in 64-byte records: 9.00 / 8.98 / 8.94 ms; 236 in 56-byte records: 8.88; at 32.1 KB only four workgroups fit a CU: 10.0 ms)
 #endif
 #ifndef CRT_LDS_VOTE_NUM
 #define CRT_LDS_VOTE_NUM 3 // an LDS-only node step when at least NUM/DEN of the lanes at a node are at a cached node
@@ -303,17 +304,22 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
     // W waves per workgroup, each on its own; with NC > 0 they share an LDS copy of the first NC nodes (breadth-first
     // numbering: the top of the tree).  The kernel is limited by the CU's address unit as much as by VALU issue (one more
     // dwordx4 load per node step costs 13 % of the frame), and about 70 % of the node visits of the headline scene go to the
-    // first ~200 nodes: those are read from LDS.  W = 4, NC = 208, SD = 16: 4 x 4.5 KB of stack + 13 KB of nodes = 31 KB,
+    // first ~240 nodes: those are read from LDS.  W = 4, NC = 236, SD = 16: 4 x 4.5 KB of stack + 13 KB of nodes = 31.6 KB,
     // five workgroups per CU = the same 20 waves as with one wave per workgroup.
     __shared__ int lds_stack_all[W][(SD + 2) * 64]; // SD = 16 when the BVH is at most 16 levels deep
-    __shared__ v4f lds_nodes[NC > 0 ? 4 * NC : 1];
+    __shared__ float lds_nodes[NC > 0 ? CRT_LDS_NODE_WORDS * NC : 1];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     int *lds_stack = lds_stack_all[wave];
     CachedNodes node_src;
     node_src.global = sc.nodes; node_src.lds = (lds_q4_ptr)lds_nodes; node_src.ncached = NC > 0 ? min((int)sc.nnodes, NC) : 0;
     if (NC > 0) {
-        const v4f *g = reinterpret_cast<const v4f *>(sc.nodes);
-        for (uint32_t k = threadIdx.x; k < 4u * (uint32_t)node_src.ncached; k += 64u * W) lds_nodes[k] = g[k];
+        // word j of the 56-byte LDS record <- word of the 64-byte device record: the four rows' xyz, then the two references
+        const float *g = reinterpret_cast<const float *>(sc.nodes);
+        for (uint32_t k = threadIdx.x; k < CRT_LDS_NODE_WORDS * (uint32_t)node_src.ncached; k += 64u * W) {
+            const uint32_t node = k / CRT_LDS_NODE_WORDS, j = k - node * CRT_LDS_NODE_WORDS;
+            const uint32_t src = j < 12u ? (j / 3u) * 4u + j % 3u : (j == 12u ? 3u : 7u);
+            lds_nodes[k] = g[16u * node + src];
+        }
         __syncthreads(); // the only workgroup barrier: from here on the waves do not meet again
     }
     // home counter of this wave: index mod 8 = workgroup mod 8 = the XCD the workgroup runs on (round robin)
@@ -555,7 +561,6 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                 }
                 if (NC > 0 && n_lds * CRT_LDS_VOTE_DEN >= n_inner * CRT_LDS_VOTE_NUM && n_lds >= n_leaf) {
                     if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_lds; } }
-#if CRT_SORTED_LDS_STEP
                     const SignOffsets so = sign_offsets(tv);
                     if (in_lds) trav_inner_lds_sorted(node_src.lds, so, tv, stack, cnt);
 #pragma unroll
@@ -564,17 +569,6 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
                         if constexpr (COUNT_WORK) { const int na = popc64(__ballot(again)); if (lane == 0) { wc[4]++; wc[5] += na; } }
                         if (again) trav_inner_lds_sorted(node_src.lds, so, tv, stack, cnt);
                     }
-#else
-                    LdsNodes top;
-                    top.lds = node_src.lds;
-                    if (in_lds) trav_inner_from(top, tv, stack, cnt);
-#pragma unroll
-                    for (int k = 1; k < CRT_LDS_STEPS_PER_VOTE; k++) {
-                        const bool again = in_lds && (unsigned)tv.cur < (unsigned)node_src.ncached;
-                        if constexpr (COUNT_WORK) { const int na = popc64(__ballot(again)); if (lane == 0) { wc[4]++; wc[5] += na; } }
-                        if (again) trav_inner_from(top, tv, stack, cnt);
-                    }
-#endif
                     CRT_LAP(clk, 7);
                 } else if (n_inner >= n_leaf) {
                     // (all lanes at a node take part: the loads cost the address unit the same whatever the number of lanes)
