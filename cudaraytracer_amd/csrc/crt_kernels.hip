@@ -1130,6 +1130,25 @@ static bool launch_whole_tree(const SceneView &sc, const CameraPOD &cam, const R
     return false;
 }
 
+// The lane kernel for a stack of SD levels: four waves per workgroup sharing an LDS copy of the top of the tree where the LDS
+// has room for one beside five workgroups' stacks (SD = 14: 272 nodes, 16: CRT_NODE_CACHE_NODES, 24: 64), else single waves.
+// (if constexpr: only the combinations that can be launched are instantiated)
+#define CRT_NODE_CACHE_NODES_14 272 // 4 x 4 KB of stack + 272 x 56 B = 31.6 KB
+template <bool CW, int SD, bool SS>
+static void launch_lanes(const SceneView &sc, const CameraPOD &cam, const RenderArgs &a, float *out, int *ids, unsigned long long *counters, uint32_t blocks,
+                         hipStream_t stream)
+{
+    if (launch_whole_tree<CW, SD, SS>(sc, cam, a, out, ids, counters, blocks, stream)) return;
+    if constexpr (SD == 14 || SD == 16 || SD == 24) {
+        constexpr int NC = SD == 14 ? CRT_NODE_CACHE_NODES_14 : SD == 16 ? CRT_NODE_CACHE_NODES : 64;
+        if (a.node_cache) {
+            hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, NC>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((render_kernel<CW, SD, SS, 1, 0>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
+}
+
 hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,
                          bool count_work, uint32_t max_waves, hipStream_t stream)
 {
@@ -1173,21 +1192,19 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
 #undef CRT_LAUNCH_POOL
         return hipGetLastError();
     }
-    // the LDS stack is sized by the tree: 16 levels (4.6 KB per wave), 24 (6.7 KB: still the 20 waves per CU the registers
-    // allow) or 32 (8.7 KB: 18 waves per CU)
+    // the LDS stack is sized by the tree: 14 levels (4 KB per wave), 16 (4.5 KB), 24 (6.5 KB: still the 20 waves per CU the registers
+    // allow) or 32 (8.5 KB: 18 waves per CU)
     const bool ss = sc.sphere_slots != 0;
     if (a.node_cache == 1 && units < max_waves) a.node_cache = 0; // a frame that does not fill the GPU: single waves spread over more CUs than groups of four (2 = always)
-    const int levels = ra.bvh_depth <= 16 ? 16 : ra.bvh_depth <= 24 ? 24 : CRT_STACK_DEPTH;
-#define CRT_LAUNCH(CW, SD, SS) do { if (launch_whole_tree<CW, SD, SS>(sc, cam, a, out, ids, counters, blocks, stream)) {} \
-                                     else if (a.node_cache && SD == 16) hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, CRT_NODE_CACHE_NODES>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters); \
-                                     else if (a.node_cache && SD == 24) hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, 64>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters); \
-                                     else hipLaunchKernelGGL((render_kernel<CW, SD, SS, 1, 0>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters); } while (0)
-#define CRT_LAUNCH_SS(CW, SD) do { if (ss) CRT_LAUNCH(CW, SD, true); else CRT_LAUNCH(CW, SD, false); } while (0)
-#define CRT_LAUNCH_SD(CW) do { if (levels == 16) CRT_LAUNCH_SS(CW, 16); else if (levels == 24) CRT_LAUNCH_SS(CW, 24); else CRT_LAUNCH_SS(CW, CRT_STACK_DEPTH); } while (0)
+    // (the whole-tree variant exists for the 16-level stack only)
+    const int levels = (ra.bvh_depth <= 14 && a.node_cache != 3) ? 14 : ra.bvh_depth <= 16 ? 16 : ra.bvh_depth <= 24 ? 24 : CRT_STACK_DEPTH;
+#define CRT_LAUNCH_SS(CW, SD) do { if (ss) launch_lanes<CW, SD, true>(sc, cam, a, out, ids, counters, blocks, stream); \
+                                   else launch_lanes<CW, SD, false>(sc, cam, a, out, ids, counters, blocks, stream); } while (0)
+#define CRT_LAUNCH_SD(CW) do { if (levels == 14) CRT_LAUNCH_SS(CW, 14); else if (levels == 16) CRT_LAUNCH_SS(CW, 16); else if (levels == 24) CRT_LAUNCH_SS(CW, 24); \
+                               else CRT_LAUNCH_SS(CW, CRT_STACK_DEPTH); } while (0)
     if (count_work) CRT_LAUNCH_SD(true); else CRT_LAUNCH_SD(false);
 #undef CRT_LAUNCH_SD
 #undef CRT_LAUNCH_SS
-#undef CRT_LAUNCH
     return hipGetLastError();
 }
 
