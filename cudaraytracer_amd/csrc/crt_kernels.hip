@@ -1131,16 +1131,19 @@ static bool launch_whole_tree(const SceneView &sc, const CameraPOD &cam, const R
 }
 
 // The lane kernel for a stack of SD levels: four waves per workgroup sharing an LDS copy of the top of the tree where the LDS
-// has room for one beside five workgroups' stacks (SD = 14: 272 nodes, 16: CRT_NODE_CACHE_NODES, 24: 64), else single waves.
+// has room for one beside five workgroups' stacks (SD = 14: 272 nodes, 16: 236, 24: 88), else single waves.
 // (if constexpr: only the combinations that can be launched are instantiated)
 #define CRT_NODE_CACHE_NODES_14 272 // 4 x 4 KB of stack + 272 x 56 B = 31.6 KB
+#ifndef CRT_NODE_CACHE_NODES_24
+#define CRT_NODE_CACHE_NODES_24 88  // 4 x 6.5 KB of stack + 88 x 56 B = 31.6 KB
+#endif
 template <bool CW, int SD, bool SS>
 static void launch_lanes(const SceneView &sc, const CameraPOD &cam, const RenderArgs &a, float *out, int *ids, unsigned long long *counters, uint32_t blocks,
                          hipStream_t stream)
 {
     if (launch_whole_tree<CW, SD, SS>(sc, cam, a, out, ids, counters, blocks, stream)) return;
     if constexpr (SD == 14 || SD == 16 || SD == 24) {
-        constexpr int NC = SD == 14 ? CRT_NODE_CACHE_NODES_14 : SD == 16 ? CRT_NODE_CACHE_NODES : 64;
+        constexpr int NC = SD == 14 ? CRT_NODE_CACHE_NODES_14 : SD == 16 ? CRT_NODE_CACHE_NODES : CRT_NODE_CACHE_NODES_24;
         if (a.node_cache) {
             hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, NC>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters);
             return;
