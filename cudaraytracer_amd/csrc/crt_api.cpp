@@ -241,7 +241,7 @@ struct Tuning {
     int pool_refill = 16;      // CRT_POOL_REFILL: pool kernel, free lanes that end a run of walk steps
     int sched_threshold = 44;  // CRT_SCHED_THRESHOLD: lanes that must wait for the shade phase before it runs
     int fetch_block = 0;       // CRT_FETCH_BLOCK: work units per trip to a block counter (a power of two, 64..65536); 0: chosen per frame
-    int node_cache = 1;        // CRT_NODE_CACHE: LDS copy of the top of the tree: 0 never, 1 when the frame fills the GPU, 2 always
+    int node_cache = 1;        // CRT_NODE_CACHE: 0 single waves, 1 chosen per frame, 2 four-wave workgroups with an LDS copy of the tree's top, 3 whole tree in one 16-wave workgroup, 4 16 + 4 wave split (crt_kernels.h)
     int stripe_bands = 1;      // CRT_STRIPE_BANDS: each block counter owns a contiguous band of the frame
     int waves_per_cu = 20;     // CRT_WAVES_PER_CU: persistent waves launched per compute unit (96 VGPRs: 5 per SIMD)
     int print_sections = 0;    // CRT_PRINT_SECTIONS: with CRT_COUNT_WORK and stats, print the section clocks
@@ -250,7 +250,7 @@ struct Tuning {
         kernel = get_env_int("CRT_KERNEL", 0) == 1 ? 1 : 0;
         pool_refill = std::min(std::max(get_env_int("CRT_POOL_REFILL", 16), 1), 63);
         sched_threshold = std::min(std::max(get_env_int("CRT_SCHED_THRESHOLD", 44), 1), 64);
-        node_cache = std::min(std::max(get_env_int("CRT_NODE_CACHE", 1), 0), 3);
+        node_cache = std::min(std::max(get_env_int("CRT_NODE_CACHE", 1), 0), 4);
         fetch_block = std::min(std::max(get_env_int("CRT_FETCH_BLOCK", 0), 0), 65536);
         stripe_bands = get_env_int("CRT_STRIPE_BANDS", 1) ? 1 : 0;
         waves_per_cu = std::min(std::max(get_env_int("CRT_WAVES_PER_CU", 20), 1), 64);
@@ -266,6 +266,7 @@ struct StreamScratch {
     hipStream_t stream = nullptr; bool used = false, recorded = false; uint64_t last_use = 0;
     unsigned long long *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr; // around the render kernel; after the last use of the set
+    SplitStreams split{ nullptr, nullptr, nullptr };           // second stream + fork / join events for the two-launch frame (crt_kernels.hip: launch_split)
     float *d_chunk_slabs = nullptr; size_t chunk_slab_floats = 0;
     float *d_stage_rgb = nullptr; size_t stage_rgb_floats = 0;
     int *d_stage_ids = nullptr; size_t stage_ids = 0;
@@ -310,6 +311,9 @@ struct DeviceScene {
             if (x.ev0) (void)hipEventDestroy(x.ev0);
             if (x.ev1) (void)hipEventDestroy(x.ev1);
             if (x.ev_done) (void)hipEventDestroy(x.ev_done);
+            if (x.split.fork) (void)hipEventDestroy(x.split.fork);
+            if (x.split.join) (void)hipEventDestroy(x.split.join);
+            if (x.split.helper) (void)hipStreamDestroy(x.split.helper);
             x = StreamScratch();
         }
         device = -1;
@@ -777,7 +781,8 @@ static size_t output_floats(const crt_render_params *p)
 // into d_rgb -- with sample chunks into the slabs, followed by the chunk-sum pass.  ev0 / ev1 (nullable) are recorded around
 // the render kernel.  Allocates nothing.
 static int enqueue_render(const crt_scene *s, const DeviceScene &d, const crt_camera *cam, const crt_render_params *p, uint32_t chunks, float *d_rgb,
-                          int *d_ids, unsigned long long *d_counters, float *d_slabs, hipEvent_t ev0, hipEvent_t ev1, hipStream_t stream)
+                          int *d_ids, unsigned long long *d_counters, float *d_slabs, hipEvent_t ev0, hipEvent_t ev1, hipStream_t stream,
+                          const SplitStreams *split)
 {
     const Tuning &t = s->tuning;
     const size_t rgb_floats = output_floats(p);
@@ -802,7 +807,7 @@ static int enqueue_render(const crt_scene *s, const DeviceScene &d, const crt_ca
     HIP_TRY(hipMemsetAsync(d_counters, 0, CRT_COUNTER_BYTES, stream));
     if (ev0) HIP_TRY(hipEventRecord(ev0, stream));
     HIP_TRY(launch_render(d.view, *reinterpret_cast<const CameraPOD *>(cam), ra, d_target, d_ids, d_counters, (p->flags & CRT_COUNT_WORK) != 0,
-                          d.cus * (uint32_t)t.waves_per_cu, stream));
+                          d.cus * (uint32_t)t.waves_per_cu, stream, t.waves_per_cu == 20 ? split : nullptr)); // (the split is 16 + 4 waves per CU)
     if (ev1) HIP_TRY(hipEventRecord(ev1, stream));
     if (chunks > 1) HIP_TRY(launch_finalize_chunks(d_slabs, chunks, rgb_floats, p->spp, (p->flags & CRT_OUT_ACCUM) != 0, d_rgb, stream));
     return CRT_OK;
@@ -822,6 +827,9 @@ static int acquire_scratch(DeviceScene &d, hipStream_t stream, uint32_t chunks, 
         HIP_TRY(hipEventCreate(&x->ev0));
         HIP_TRY(hipEventCreate(&x->ev1));
         HIP_TRY(hipEventCreate(&x->ev_done));
+        HIP_TRY(hipStreamCreateWithFlags(&x->split.helper, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&x->split.fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&x->split.join, hipEventDisableTiming));
     }
     if (chunks > 1) {
         const size_t need = chunk_slab_floats(rgb_floats, chunks);
@@ -906,7 +914,7 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
         if (p->tile_ranks > 1) HIP_TRY(hipMemcpyAsync(d_ids, out_ids, npix * sizeof(int), hipMemcpyHostToDevice, stream));
     }
 
-    if ((rc = enqueue_render(s, d, cam, p, chunks, d_rgb, d_ids, x->d_counters, x->d_chunk_slabs, x->ev0, x->ev1, stream))) return rc;
+    if ((rc = enqueue_render(s, d, cam, p, chunks, d_rgb, d_ids, x->d_counters, x->d_chunk_slabs, x->ev0, x->ev1, stream, &x->split))) return rc;
     HIP_TRY(hipEventRecord(x->ev_done, stream));
     x->recorded = true;
 
@@ -947,7 +955,7 @@ extern "C" int crt_render_noalloc(const crt_scene *cs, const crt_camera *cam, co
     hipStream_t stream = (hipStream_t)p->stream;
     unsigned long long *d_counters = (unsigned long long *)scratch;
     float *d_slabs = (float *)(scratch + CRT_NOALLOC_SLAB_OFFSET);
-    if ((rc = enqueue_render(s, d, cam, p, chunks, out_rgb, out_ids, d_counters, d_slabs, nullptr, nullptr, stream))) return rc;
+    if ((rc = enqueue_render(s, d, cam, p, chunks, out_rgb, out_ids, d_counters, d_slabs, nullptr, nullptr, stream, nullptr))) return rc; // (no second stream: nothing may be created here)
     if (out_rays) HIP_TRY(hipMemcpyAsync(out_rays, d_counters, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
     return CRT_OK;
 }
@@ -1170,7 +1178,7 @@ extern "C" int crt_render_multi(const crt_scene *cs, const crt_camera *cam, cons
         if (m.done_recorded[set]) HIP_TRY(hipStreamWaitEvent(st, m.frame_done[set], 0));
         if ((rc = acquire_scratch(s->dev[r], st, rank_chunks, part, &x[r]))) return rc;
         q[r].stream = st;
-        if ((rc = enqueue_render(s, s->dev[r], cam, &q[r], rank_chunks, k.d_local[set], d_ids, x[r]->d_counters, x[r]->d_chunk_slabs, x[r]->ev0, x[r]->ev1, st)))
+        if ((rc = enqueue_render(s, s->dev[r], cam, &q[r], rank_chunks, k.d_local[set], d_ids, x[r]->d_counters, x[r]->d_chunk_slabs, x[r]->ev0, x[r]->ev1, st, &x[r]->split)))
             return rc;
         HIP_TRY(hipEventRecord(x[r]->ev_done, st));
         x[r]->recorded = true;

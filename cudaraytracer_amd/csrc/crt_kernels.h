@@ -24,7 +24,8 @@ struct RenderArgs {
     uint32_t chunk_shift;     // log2(chunks)                                  (set by launch_render)
     uint32_t tiles_x_magic;   // floor(2^32 / tiles_x) for the kernel's tile -> (column, row) division (set by launch_render)
     uint32_t blocks_per_stripe; // in: non-zero = each block counter owns a contiguous band of the frame; launch_render sets the count
-    uint32_t node_cache;      // four waves per workgroup sharing an LDS copy of the top of the tree (trees up to 24 deep): 0 never, 1 when the frame fills the GPU, 2 always
+    uint32_t node_cache;      // LDS copy of the top of the tree: 0 never (single waves), 1 chosen by the frame (launch_render), 2 four-wave workgroups always,
+                              // 3 one 16-wave workgroup per CU with the whole tree (small trees), 4 the 16 + 4 wave split whenever it can be launched
     uint32_t kernel;          // RK_*
     uint32_t bvh_depth;       // levels of the triangle BVH (selects the LDS stack size)
     uint32_t fetch_shift;     // log2 of the work units a wave takes from a block counter at a time; in: 0 = launch_render chooses
@@ -51,8 +52,11 @@ struct RenderArgs {
 // before that).
 hipError_t noalloc_scratch_init(int device);
 void *noalloc_scratch_ptr(int device);
+// A second stream and two events of the caller's (created ahead of time, on the device of `stream`): with them launch_render may
+// split a frame over two concurrent launches that share the frame's work queue (crt_kernels.hip: launch_split).  nullptr: one launch.
+struct SplitStreams { hipStream_t helper; hipEvent_t fork, join; };
 hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,
-                         bool count_work, uint32_t max_waves, hipStream_t stream);
+                         bool count_work, uint32_t max_waves, hipStream_t stream, const SplitStreams *split = nullptr);
 hipError_t launch_untile(const float *compact_all, uint32_t width, uint32_t height, uint32_t tile_ranks, float *out, hipStream_t stream);
 hipError_t launch_finalize_chunks(const float *slabs, uint32_t chunks, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream); // slabs [64-pixel block][chunk][64][3], n = 3 x pixels
 hipError_t launch_sum_frames(const float *frames, uint32_t count, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream);      // frames n floats apart

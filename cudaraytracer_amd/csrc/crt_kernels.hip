@@ -285,17 +285,17 @@ static_assert(CRT_WORK_STRIPES == 64u, "the order in which a wave visits the blo
 #ifndef CRT_LDS_STEPS_PER_VOTE
 #define CRT_LDS_STEPS_PER_VOTE 4 // node steps per vote when the nodes come from the LDS copy
 #endif
+#ifndef CRT_WHOLE_TREE_NODES
+#define CRT_WHOLE_TREE_NODES 1344 // 16 x 4.6 KB of stack + 84 KB of nodes = 156 KB: one workgroup per CU
+#endif
 #ifndef CRT_WAVES_PER_EU
 #define CRT_WAVES_PER_EU 5 // 512 VGPRs / 5 waves -> 96 registers per lane; the few spills this forces sit on the rare tie path
 #endif
 // (a 16-wave workgroup is the whole-tree-in-LDS variant: one workgroup per CU = 4 waves per SIMD = 128 registers per lane)
 #if CRT_WAVES_PER_EU > 0
-#define CRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(W == 16 ? 4 : CRT_WAVES_PER_EU, W == 16 ? 4 : CRT_WAVES_PER_EU)))
+#define CRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu((W == 16 && NC == CRT_WHOLE_TREE_NODES) ? 4 : CRT_WAVES_PER_EU, (W == 16 && NC == CRT_WHOLE_TREE_NODES) ? 4 : CRT_WAVES_PER_EU)))
 #else
 #define CRT_OCCUPANCY_ATTR
-#endif
-#ifndef CRT_WHOLE_TREE_NODES
-#define CRT_WHOLE_TREE_NODES 1344 // 16 x 4.6 KB of stack + 84 KB of nodes = 156 KB: one workgroup per CU
 #endif
 template <bool COUNT_WORK, int SD, bool SS, int W, int NC>
 __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
@@ -1130,6 +1130,37 @@ static bool launch_whole_tree(const SceneView &sc, const CameraPOD &cam, const R
     return false;
 }
 
+// One copy of the tree's top per CU instead of five.  Five 4-wave workgroups per CU hold five copies of the same ~270 nodes, and
+// 80 of the CU's 160 KB of LDS are stacks.  A workgroup cannot have more than 16 waves, so a CU gets ONE 16-wave workgroup whose
+// LDS copy holds the whole node array of a small tree (1328 nodes beside a 14-level stack, 1176 beside 16 levels) and ONE 4-wave
+// workgroup with a small copy: two launches on two streams that take their work from the same block counters of the same frame,
+// 16 + 4 = the same 20 waves per CU (4 x 104 + 96 registers per SIMD lane).  On the headline frame no wave of the large
+// workgroup ever fetches a node from device memory: 8.33 ms per step against 8.87.  Both launches are the
+// same kernel with other template arguments, so the frame is the same bit for bit.  The small copy must stay below 32 KB per
+// workgroup: above it the compiler sees an LDS-limited occupancy of 4 waves per SIMD, gives the kernel 128 registers, and the
+// workgroup no longer fits beside the large one (16 ms).
+#define CRT_SPLIT_A_NODES_14 1328 // 16 x 4 KB   of stack + 1328 x 56 B = 136.6 KB
+#define CRT_SPLIT_B_NODES_14 112  //  4 x 4 KB   of stack +  112 x 56 B =  22.1 KB
+#define CRT_SPLIT_A_NODES_16 1176 // 16 x 4.5 KB of stack + 1176 x 56 B = 136.3 KB
+#define CRT_SPLIT_B_NODES_16 76   //  4 x 4.5 KB of stack +   76 x 56 B =  22.2 KB
+template <bool CW, int SD, bool SS>
+static bool launch_split(const SceneView &sc, const CameraPOD &cam, const RenderArgs &a, float *out, int *ids, unsigned long long *counters, uint32_t blocks,
+                         hipStream_t stream, const SplitStreams *split)
+{
+    if constexpr (SD == 14 || SD == 16) {
+        if (!split || !split->helper) return false;
+        constexpr int NA = SD == 14 ? CRT_SPLIT_A_NODES_14 : CRT_SPLIT_A_NODES_16, NB = SD == 14 ? CRT_SPLIT_B_NODES_14 : CRT_SPLIT_B_NODES_16;
+        const uint32_t cus = (blocks + 19u) / 20u; // blocks = persistent waves, 20 per CU
+        // the small workgroups start behind whatever the caller's stream holds, the caller's stream goes on behind them
+        if (hipEventRecord(split->fork, stream) != hipSuccess || hipStreamWaitEvent(split->helper, split->fork, 0) != hipSuccess) return false;
+        hipLaunchKernelGGL((render_kernel<CW, SD, SS, 16, NA>), dim3(cus), dim3(1024), 0, stream, sc, cam, a, out, ids, counters);
+        hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, NB>), dim3(cus), dim3(256), 0, split->helper, sc, cam, a, out, ids, counters);
+        if (hipEventRecord(split->join, split->helper) != hipSuccess || hipStreamWaitEvent(stream, split->join, 0) != hipSuccess) return false;
+        return true;
+    }
+    return false;
+}
+
 // The lane kernel for a stack of SD levels: four waves per workgroup sharing an LDS copy of the top of the tree where the LDS
 // has room for one beside five workgroups' stacks (SD = 14: 272 nodes, 16: 236, 24: 88), else single waves.
 // (if constexpr: only the combinations that can be launched are instantiated)
@@ -1139,9 +1170,10 @@ static bool launch_whole_tree(const SceneView &sc, const CameraPOD &cam, const R
 #endif
 template <bool CW, int SD, bool SS>
 static void launch_lanes(const SceneView &sc, const CameraPOD &cam, const RenderArgs &a, float *out, int *ids, unsigned long long *counters, uint32_t blocks,
-                         hipStream_t stream)
+                         hipStream_t stream, const SplitStreams *split)
 {
     if (launch_whole_tree<CW, SD, SS>(sc, cam, a, out, ids, counters, blocks, stream)) return;
+    if (a.node_cache == 4 && launch_split<CW, SD, SS>(sc, cam, a, out, ids, counters, blocks, stream, split)) return;
     if constexpr (SD == 14 || SD == 16 || SD == 24) {
         constexpr int NC = SD == 14 ? CRT_NODE_CACHE_NODES_14 : SD == 16 ? CRT_NODE_CACHE_NODES : CRT_NODE_CACHE_NODES_24;
         if (a.node_cache) {
@@ -1153,7 +1185,7 @@ static void launch_lanes(const SceneView &sc, const CameraPOD &cam, const Render
 }
 
 hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,
-                         bool count_work, uint32_t max_waves, hipStream_t stream)
+                         bool count_work, uint32_t max_waves, hipStream_t stream, const SplitStreams *split)
 {
     const uint32_t ntiles = ra.tiles_x * ra.tiles_y;
     const uint32_t local_tiles = (ntiles + ra.tile_ranks - 1 - ra.tile_rank) / ra.tile_ranks; // tiles k = b*ranks + rank < ntiles
@@ -1198,11 +1230,15 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     // the LDS stack is sized by the tree: 14 levels (4 KB per wave), 16 (4.5 KB), 24 (6.5 KB: still the 20 waves per CU the registers
     // allow) or 32 (8.5 KB: 18 waves per CU)
     const bool ss = sc.sphere_slots != 0;
-    if (a.node_cache == 1 && units < max_waves) a.node_cache = 0; // a frame that does not fill the GPU: single waves spread over more CUs than groups of four (2 = always)
+    // node_cache = 1, chosen by the frame: one that does not fill the GPU spreads better as single waves (0); one that fills it many
+    // times over takes the 16 + 4 split where the tree allows it (4: the large workgroups' LDS copies and their 16 waves that
+    // must all finish before the slot is free only pay on long frames); else four-wave workgroups (2)
+    if (a.node_cache == 1) a.node_cache = units < max_waves ? 0u : (units >= 8ull * max_waves && split && split->helper && ra.bvh_depth <= 16 && blocks == max_waves) ? 4u : 2u;
+    if (a.node_cache == 4 && !(split && split->helper && ra.bvh_depth <= 16)) a.node_cache = 2; // (asked for by name: small frames too, the tests do)
     // (the whole-tree variant exists for the 16-level stack only)
     const int levels = (ra.bvh_depth <= 14 && a.node_cache != 3) ? 14 : ra.bvh_depth <= 16 ? 16 : ra.bvh_depth <= 24 ? 24 : CRT_STACK_DEPTH;
-#define CRT_LAUNCH_SS(CW, SD) do { if (ss) launch_lanes<CW, SD, true>(sc, cam, a, out, ids, counters, blocks, stream); \
-                                   else launch_lanes<CW, SD, false>(sc, cam, a, out, ids, counters, blocks, stream); } while (0)
+#define CRT_LAUNCH_SS(CW, SD) do { if (ss) launch_lanes<CW, SD, true>(sc, cam, a, out, ids, counters, blocks, stream, split); \
+                                   else launch_lanes<CW, SD, false>(sc, cam, a, out, ids, counters, blocks, stream, split); } while (0)
 #define CRT_LAUNCH_SD(CW) do { if (levels == 14) CRT_LAUNCH_SS(CW, 14); else if (levels == 16) CRT_LAUNCH_SS(CW, 16); else if (levels == 24) CRT_LAUNCH_SS(CW, 24); \
                                else CRT_LAUNCH_SS(CW, CRT_STACK_DEPTH); } while (0)
     if (count_work) CRT_LAUNCH_SD(true); else CRT_LAUNCH_SD(false);

@@ -57,11 +57,12 @@ def scenes(capi):
     return s
 
 
-@pytest.fixture(params=["0", "2", "3"], ids=["one-wave-groups", "lds-node-copy", "whole-tree-in-lds"])
+@pytest.fixture(params=["0", "2", "3", "4"], ids=["one-wave-groups", "lds-node-copy", "whole-tree-in-lds", "split-16-4"])
 def node_cache(request, monkeypatch):
-    """Runs a GPU test with both kernel variants: one wave per workgroup (CRT_NODE_CACHE=0) and four waves sharing an LDS copy
-    of the top of the tree (CRT_NODE_CACHE=2: always; the default, 1, picks it only for frames that fill the GPU, which
-    test-sized frames do not), and one 16-wave workgroup per CU holding the whole node array in LDS (CRT_NODE_CACHE=3: small trees
-    only; larger ones fall back to the four-wave variant)."""
+    """Runs a GPU test with every kernel variant: one wave per workgroup (CRT_NODE_CACHE=0), four waves sharing an LDS copy
+    of the top of the tree (CRT_NODE_CACHE=2: always), one 16-wave workgroup per CU holding the whole node array in LDS
+    (CRT_NODE_CACHE=3: small trees only; larger ones fall back to the four-wave variant), and the two-launch frame of one
+    16-wave and one 4-wave workgroup per CU on one work queue (CRT_NODE_CACHE=4; trees deeper than 16 levels fall back).  The
+    default, 1, chooses by the frame: test-sized frames get single waves, the benchmark's the split."""
     monkeypatch.setenv("CRT_NODE_CACHE", request.param)
     return request.param

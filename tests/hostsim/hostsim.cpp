@@ -6,7 +6,7 @@
 #include "../../cudaraytracer_amd/csrc/crt_api.cpp"
 
 namespace crt {
-hipError_t launch_render(const SceneView &, const CameraPOD &, const RenderArgs &, float *, int *, unsigned long long *, bool, uint32_t, hipStream_t)
+hipError_t launch_render(const SceneView &, const CameraPOD &, const RenderArgs &, float *, int *, unsigned long long *, bool, uint32_t, hipStream_t, const SplitStreams *)
 {
     return hipErrorNoDevice;
 }
