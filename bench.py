@@ -133,8 +133,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-in-flight", type=int, choices=[0, 1, 2, 3], default=0,
                     help="n > 1: consecutive frames rotate over n HIP streams (dist.py), so one frame's last waves drain while the next "
-                         "frame's first waves start; 1: one frame at a time; 0 (default): 2, and 3 when 4 or more ranks share the "
-                         "frame (a rank's share is then short against the kernel's ramp-up and drain: tools/rank_share.py, DESIGN.md section 5)")
+                         "frame's first waves start; 1: one frame at a time; 0 (default): 2.  (A third frame in flight helped short "
+                         "rank-frames by 2-3 %% while a CU held five 4-wave workgroups; with one 16-wave and one 4-wave workgroup per CU "
+                         "it costs 5 %%: tools/rank_share.py, DESIGN.md section 5)")
     ap.add_argument("--mode", choices=["tile", "sample"], default="tile")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cats")
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug; invalidates the headline number)")
@@ -147,7 +148,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    in_flight = args.frames_in_flight or (2 if world < 4 else 3)
+    in_flight = args.frames_in_flight or 2
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
