@@ -1143,13 +1143,16 @@ static bool launch_whole_tree(const SceneView &sc, const CameraPOD &cam, const R
 #define CRT_SPLIT_B_NODES_14 112  //  4 x 4 KB   of stack +  112 x 56 B =  22.1 KB
 #define CRT_SPLIT_A_NODES_16 1176 // 16 x 4.5 KB of stack + 1176 x 56 B = 136.3 KB
 #define CRT_SPLIT_B_NODES_16 76   //  4 x 4.5 KB of stack +   76 x 56 B =  22.2 KB
+#define CRT_SPLIT_A_NODES_24 508  // 16 x 6.5 KB of stack +  508 x 56 B = 131.8 KB
+#define CRT_SPLIT_B_NODES_24 16   //  4 x 6.5 KB of stack +   16 x 56 B =  26.9 KB
 template <bool CW, int SD, bool SS>
 static bool launch_split(const SceneView &sc, const CameraPOD &cam, const RenderArgs &a, float *out, int *ids, unsigned long long *counters, uint32_t blocks,
                          hipStream_t stream, const SplitStreams *split)
 {
-    if constexpr (SD == 14 || SD == 16) {
+    if constexpr (SD == 14 || SD == 16 || SD == 24) {
         if (!split || !split->helper) return false;
-        constexpr int NA = SD == 14 ? CRT_SPLIT_A_NODES_14 : CRT_SPLIT_A_NODES_16, NB = SD == 14 ? CRT_SPLIT_B_NODES_14 : CRT_SPLIT_B_NODES_16;
+        constexpr int NA = SD == 14 ? CRT_SPLIT_A_NODES_14 : SD == 16 ? CRT_SPLIT_A_NODES_16 : CRT_SPLIT_A_NODES_24;
+        constexpr int NB = SD == 14 ? CRT_SPLIT_B_NODES_14 : SD == 16 ? CRT_SPLIT_B_NODES_16 : CRT_SPLIT_B_NODES_24;
         const uint32_t cus = (blocks + 19u) / 20u; // blocks = persistent waves, 20 per CU
         // the small workgroups start behind whatever the caller's stream holds, the caller's stream goes on behind them
         if (hipEventRecord(split->fork, stream) != hipSuccess || hipStreamWaitEvent(split->helper, split->fork, 0) != hipSuccess) return false;
@@ -1233,8 +1236,8 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     // node_cache = 1, chosen by the frame: one that does not fill the GPU spreads better as single waves (0); one that fills it many
     // times over takes the 16 + 4 split where the tree allows it (4: the large workgroups' LDS copies and their 16 waves that
     // must all finish before the slot is free only pay on long frames); else four-wave workgroups (2)
-    if (a.node_cache == 1) a.node_cache = units < max_waves ? 0u : (units >= 8ull * max_waves && split && split->helper && ra.bvh_depth <= 16 && blocks == max_waves) ? 4u : 2u;
-    if (a.node_cache == 4 && !(split && split->helper && ra.bvh_depth <= 16)) a.node_cache = 2; // (asked for by name: small frames too, the tests do)
+    if (a.node_cache == 1) a.node_cache = units < max_waves ? 0u : (units >= 8ull * max_waves && split && split->helper && ra.bvh_depth <= 24 && blocks == max_waves) ? 4u : 2u;
+    if (a.node_cache == 4 && !(split && split->helper && ra.bvh_depth <= 24)) a.node_cache = 2; // (asked for by name: small frames too, the tests do)
     // (the whole-tree variant exists for the 16-level stack only)
     const int levels = (ra.bvh_depth <= 14 && a.node_cache != 3) ? 14 : ra.bvh_depth <= 16 ? 16 : ra.bvh_depth <= 24 ? 24 : CRT_STACK_DEPTH;
 #define CRT_LAUNCH_SS(CW, SD) do { if (ss) launch_lanes<CW, SD, true>(sc, cam, a, out, ids, counters, blocks, stream, split); \
