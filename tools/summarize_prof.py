@@ -1,5 +1,11 @@
 """Summarise a gpurun_out/prof_<tag>/ directory (profiles/run_rocprof.sh) into profiles/<name>/: kernel stats csv + a json
-of the per-launch PMC averages of render_kernel<false> with the derived figures DESIGN.md quotes."""
+of the per-FRAME PMC figures of render_kernel<false> with the derived figures DESIGN.md quotes.
+
+A frame that fills the GPU runs as two render kernels at once (the 16 + 4 split): rocprofv3 serialises
+dispatches while it collects counters, so in the PMC passes whichever of the two starts first does the whole frame and the other
+finds the work queue empty.  Counters are therefore summed over both kernels of a frame (instruction, lane and byte counts do
+not depend on which kernel did the work); the frame's duration comes from the kernel trace, where the two run together
+(first start to last end), and the shader clock from the PMC pass's own GRBM_GUI_ACTIVE and timestamps."""
 import collections
 import csv
 import json
@@ -13,23 +19,39 @@ shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(d
 out = {}
 for f in ["pmc_sq1", "pmc_sq2", "pmc_tcc1", "pmc_tcc2"]:
     rows = list(csv.DictReader(open(os.path.join(src, f, f + "_counter_collection.csv"))))
-    agg = collections.defaultdict(list)
+    agg = collections.defaultdict(float)
+    per_name = collections.defaultdict(set)
+    spans = {}
     for r in rows:
         if "kernel<false" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            out["LDS_Block_Size"], out["Scratch_Size"], out["Grid_Size"] = r["LDS_Block_Size"], r["Scratch_Size"], r["Grid_Size"]
+            agg[r["Counter_Name"]] += float(r["Counter_Value"])
+            per_name[r["Kernel_Name"]].add(r["Dispatch_Id"])
+            spans[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            out.setdefault("kernels", {})[r["Kernel_Name"].split("(")[0]] = {"LDS_Block_Size": r["LDS_Block_Size"], "Scratch_Size": r["Scratch_Size"],
+                                                                          "Grid_Size": r["Grid_Size"], "VGPR_Count": r["VGPR_Count"]}
+    frames = max(len(v) for v in per_name.values())
     for k, v in agg.items():
-        out[k] = sum(v) / len(v)
-for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))):
-    if "kernel<false" in r["Name"]:
-        out["kernel_avg_ns"], out["kernel_calls"] = float(r["AverageNs"]), int(r["Calls"])
-cycles = out["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+        out[k] = v / frames
+    if "GRBM_GUI_ACTIVE" in agg:
+        out["pmc_pass_ns_per_frame"] = sum(spans.values()) / frames
+# the frame's duration where its kernels run together: the kernel trace, first start to last end of each frame
+disp = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in
+               csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_trace.csv"))) if "kernel<false" in r["Kernel_Name"]))
+frames_t = []
+for s0, e0, name in disp:
+    if frames_t and s0 < frames_t[-1][1] and name not in frames_t[-1][2]:
+        frames_t[-1][1] = max(frames_t[-1][1], e0); frames_t[-1][2].add(name)
+    else:
+        frames_t.append([s0, e0, {name}])
+out["kernel_avg_ns"], out["kernel_calls"] = sum(e - s for s, e, _ in frames_t) / len(frames_t), len(frames_t)
+out["kernels_per_frame"] = len(frames_t[0][2])
+clock_ghz = out["GRBM_GUI_ACTIVE"] / 8.0 / out["pmc_pass_ns_per_frame"]  # summed over the 8 XCDs
+cycles = clock_ghz * out["kernel_avg_ns"]
 out["derived"] = {
-    "shader_clock_GHz": cycles / out["kernel_avg_ns"],
+    "shader_clock_GHz": clock_ghz,
     "valu_lane_utilisation": out["SQ_THREAD_CYCLES_VALU"] / (out["SQ_ACTIVE_INST_VALU"] * 64.0),
     "valu_busy_fraction_of_simd_time": out["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024.0 * cycles),   # ACTIVE_INST counts quad-cycles
-    "wave_slot_occupancy_of_32_per_cu": out["SQ_WAVE_CYCLES"] * 4.0 / (256.0 * 32.0 * cycles),
-    "wave_time_waiting_fraction": out["SQ_WAIT_ANY"] / out["SQ_WAVE_CYCLES"],
+    "wave_time_waiting_fraction_serialised": out["SQ_WAIT_ANY"] / out["SQ_WAVE_CYCLES"],
     "hbm_bytes_per_launch": out["FETCH_SIZE"] * 1024.0 * 2.0 + out["WRITE_SIZE"] * 1024.0,          # FETCH_SIZE x2: gfx950 calibration
     "l2_hit_rate": out["TCC_HIT_sum"] / (out["TCC_HIT_sum"] + out["TCC_MISS_sum"]),
     "valu_instructions_per_launch": out["SQ_INSTS_VALU"],
