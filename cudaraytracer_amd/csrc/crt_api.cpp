@@ -278,6 +278,7 @@ struct DeviceScene {
     void *d_nodes = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_shades = nullptr, *d_normals = nullptr;
     uint32_t cus = 0; // compute units: the persistent grid is cus x Tuning::waves_per_cu waves
     SceneView view{};
+    SplitStreams noalloc_split{ nullptr, nullptr, nullptr }; // crt_render_noalloc's helper stream + events, made at commit (it may create nothing itself)
     static constexpr int MAX_STREAMS = 4;
     StreamScratch scratch[MAX_STREAMS];
     uint64_t use_clock = 0;
@@ -303,6 +304,10 @@ struct DeviceScene {
         void *ptrs[] = { d_nodes, d_tris, d_spheres, d_shades, d_normals };
         for (void *p : ptrs) if (p) (void)hipFree(p);
         d_nodes = d_tris = d_spheres = d_shades = d_normals = nullptr;
+        if (noalloc_split.fork) (void)hipEventDestroy(noalloc_split.fork);
+        if (noalloc_split.join) (void)hipEventDestroy(noalloc_split.join);
+        if (noalloc_split.helper) (void)hipStreamDestroy(noalloc_split.helper);
+        noalloc_split = SplitStreams{ nullptr, nullptr, nullptr };
         for (StreamScratch &x : scratch) {
             if (x.d_counters) (void)hipFree(x.d_counters);
             if (x.d_chunk_slabs) (void)hipFree(x.d_chunk_slabs);
@@ -630,6 +635,11 @@ static int upload_replica(crt_scene *s, DeviceScene &d, int device)
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     d.cus = (uint32_t)prop.multiProcessorCount;
     HIP_TRY(noalloc_scratch_init(device)); // the device's copy of the static scratch of crt_render_noalloc (crt_kernels.hip)
+    if (!d.noalloc_split.helper) {         // ... and the second stream of its two-launch frames (crt_kernels.hip: launch_split)
+        HIP_TRY(hipStreamCreateWithFlags(&d.noalloc_split.helper, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&d.noalloc_split.fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&d.noalloc_split.join, hipEventDisableTiming));
+    }
     SceneView &v = d.view;
     v.nodes = (const q4 *)d.d_nodes; v.tris = (const q4 *)d.d_tris; v.spheres = (const Sphere *)d.d_spheres;
     v.shades = (const Shade *)d.d_shades; v.normals = (const q4 *)d.d_normals;
@@ -936,7 +946,8 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
 
 // crt_render for callers that cannot allocate (HIP graph capture, tight serving loops): the counters and the chunk slabs
 // live in the device's copy of a static __device__ array (crt_kernels.hip), whose address was taken when the scene was
-// committed to that device.  No hipMalloc / hipFree / event creation / host synchronisation here.
+// committed to that device, as were the helper stream and the two events of a two-launch frame (launch_split: event record /
+// stream wait only).  No hipMalloc / hipFree / stream or event creation / host synchronisation here.
 extern "C" int crt_render_noalloc(const crt_scene *cs, const crt_camera *cam, const crt_render_params *p, float *out_rgb, int32_t *out_ids,
                                   uint64_t *out_rays)
 {
@@ -955,7 +966,7 @@ extern "C" int crt_render_noalloc(const crt_scene *cs, const crt_camera *cam, co
     hipStream_t stream = (hipStream_t)p->stream;
     unsigned long long *d_counters = (unsigned long long *)scratch;
     float *d_slabs = (float *)(scratch + CRT_NOALLOC_SLAB_OFFSET);
-    if ((rc = enqueue_render(s, d, cam, p, chunks, out_rgb, out_ids, d_counters, d_slabs, nullptr, nullptr, stream, nullptr))) return rc; // (no second stream: nothing may be created here)
+    if ((rc = enqueue_render(s, d, cam, p, chunks, out_rgb, out_ids, d_counters, d_slabs, nullptr, nullptr, stream, &d.noalloc_split))) return rc; // (the second stream and its events were made at commit)
     if (out_rays) HIP_TRY(hipMemcpyAsync(out_rays, d_counters, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
     return CRT_OK;
 }

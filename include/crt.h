@@ -196,8 +196,9 @@ int crt_render(const crt_scene *s, const crt_camera *cam, const crt_render_param
  * Same frame, same kernels, same bits as crt_render, but the work counters and the sample-chunk slabs live in a static
  * __device__ array of the library (16.6 KB of counters + CRT_NOALLOC_SLAB_BYTES = 32 MiB of slabs, one copy per GPU the
  * library runs on, held until the process ends) whose per-device address is taken when a scene is committed to the
- * device.  The call makes no hipMalloc / hipFree / event creation and never waits on the host: everything is enqueued on
- * p->stream.  out_rgb and out_ids (nullable) must be device pointers; out_rays (nullable, device pointer) receives the
+ * device.  The call makes no hipMalloc / hipFree / stream or event creation and never waits on the host: everything is
+ * enqueued on p->stream (a large frame runs as two launches, the second on a helper stream of the scene that is forked from
+ * and joined to p->stream by two events; stream and events are made at commit).  out_rgb and out_ids (nullable) must be device pointers; out_rays (nullable, device pointer) receives the
  * frame's path-segment count.  Limits: with sample_chunks > 1, output pixels (rounded up to a multiple of 64) x 3 x sample_chunks x 4 bytes
  * must fit the 32 MiB of slabs (CRT_ERR_LIMIT otherwise; sample_chunks <= 1 needs no slab and has no size limit).  There is no
  * crt_stats and no CRT_COUNT_WORK readout.  Every call on a GPU shares that GPU's array: the call clears what must start

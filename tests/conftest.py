@@ -62,7 +62,7 @@ def node_cache(request, monkeypatch):
     """Runs a GPU test with every kernel variant: one wave per workgroup (CRT_NODE_CACHE=0), four waves sharing an LDS copy
     of the top of the tree (CRT_NODE_CACHE=2: always), one 16-wave workgroup per CU holding the whole node array in LDS
     (CRT_NODE_CACHE=3: small trees only; larger ones fall back to the four-wave variant), and the two-launch frame of one
-    16-wave and one 4-wave workgroup per CU on one work queue (CRT_NODE_CACHE=4; trees deeper than 16 levels fall back).  The
+    16-wave and one 4-wave workgroup per CU on one work queue (CRT_NODE_CACHE=4; trees deeper than 24 levels fall back).  The
     default, 1, chooses by the frame: test-sized frames get single waves, the benchmark's the split."""
     monkeypatch.setenv("CRT_NODE_CACHE", request.param)
     return request.param

@@ -23,8 +23,10 @@ def _both(capi, s, cam, W, H, spp, chunks, **kw):
     return got
 
 
-def test_noalloc_matches_crt_render_twice_in_a_row(capi, scenes):
+@pytest.mark.parametrize("node_cache", ["1", "4"])  # 4: every frame as two launches on two streams (the helper stream is made at commit)
+def test_noalloc_matches_crt_render_twice_in_a_row(capi, scenes, monkeypatch, node_cache):
     import torch
+    monkeypatch.setenv("CRT_NODE_CACHE", node_cache)
     s = scenes.build(scenes.cats(), 0)
     # first call: sample chunks (the slabs of the static scratch are used), 480 x 270 x 4 chunks = 6.2 MB of slabs
     _, cam = scenes.make_camera(480)
