@@ -278,7 +278,12 @@ struct DeviceScene {
     void *d_nodes = nullptr, *d_tris = nullptr, *d_spheres = nullptr, *d_shades = nullptr, *d_normals = nullptr;
     uint32_t cus = 0; // compute units: the persistent grid is cus x Tuning::waves_per_cu waves
     SceneView view{};
-    SplitStreams noalloc_split{ nullptr, nullptr, nullptr }; // crt_render_noalloc's helper stream + events, made at commit (it may create nothing itself)
+    // The helper stream of the two-launch frames (crt_kernels.hip: launch_split), ONE per device and scene, shared by every caller
+    // stream, plus crt_render_noalloc's fork / join events (made at commit: that call may create nothing itself).  One helper for
+    // all streams on purpose: with two frames in flight the small workgroups of frame k + 1 must not start before those of frame k
+    // have left -- a CU that the large workgroup of frame k has just left would otherwise take several of them, and the large
+    // workgroup of frame k + 1 would find no room there for the whole frame (measured: 8.8-9.2 ms per step instead of 8.3).
+    SplitStreams noalloc_split{ nullptr, nullptr, nullptr };
     static constexpr int MAX_STREAMS = 4;
     StreamScratch scratch[MAX_STREAMS];
     uint64_t use_clock = 0;
@@ -307,7 +312,7 @@ struct DeviceScene {
         if (noalloc_split.fork) (void)hipEventDestroy(noalloc_split.fork);
         if (noalloc_split.join) (void)hipEventDestroy(noalloc_split.join);
         if (noalloc_split.helper) (void)hipStreamDestroy(noalloc_split.helper);
-        noalloc_split = SplitStreams{ nullptr, nullptr, nullptr };
+        noalloc_split = SplitStreams{ nullptr, nullptr, nullptr }; // (the per-stream sets below only borrowed the helper stream)
         for (StreamScratch &x : scratch) {
             if (x.d_counters) (void)hipFree(x.d_counters);
             if (x.d_chunk_slabs) (void)hipFree(x.d_chunk_slabs);
@@ -318,7 +323,6 @@ struct DeviceScene {
             if (x.ev_done) (void)hipEventDestroy(x.ev_done);
             if (x.split.fork) (void)hipEventDestroy(x.split.fork);
             if (x.split.join) (void)hipEventDestroy(x.split.join);
-            if (x.split.helper) (void)hipStreamDestroy(x.split.helper);
             x = StreamScratch();
         }
         device = -1;
@@ -617,6 +621,16 @@ static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
     return CRT_OK;
 }
 
+// The fork / join events of a two-launch frame (crt_kernels.hip: launch_split) around the device's helper stream (nullptr: made here).
+static hipError_t make_split_streams(SplitStreams &sp, hipStream_t helper)
+{
+    hipError_t e;
+    sp.helper = helper;
+    if (!sp.helper && (e = hipStreamCreateWithFlags(&sp.helper, hipStreamNonBlocking)) != hipSuccess) return e;
+    if ((e = hipEventCreateWithFlags(&sp.fork, hipEventDisableTiming)) != hipSuccess) return e;
+    return hipEventCreateWithFlags(&sp.join, hipEventDisableTiming);
+}
+
 // Device side of a commit: one copy of the prepared scene on `device`.
 static int upload_replica(crt_scene *s, DeviceScene &d, int device)
 {
@@ -636,9 +650,7 @@ static int upload_replica(crt_scene *s, DeviceScene &d, int device)
     d.cus = (uint32_t)prop.multiProcessorCount;
     HIP_TRY(noalloc_scratch_init(device)); // the device's copy of the static scratch of crt_render_noalloc (crt_kernels.hip)
     if (!d.noalloc_split.helper) {         // ... and the second stream of its two-launch frames (crt_kernels.hip: launch_split)
-        HIP_TRY(hipStreamCreateWithFlags(&d.noalloc_split.helper, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&d.noalloc_split.fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&d.noalloc_split.join, hipEventDisableTiming));
+        HIP_TRY(make_split_streams(d.noalloc_split, nullptr));
     }
     SceneView &v = d.view;
     v.nodes = (const q4 *)d.d_nodes; v.tris = (const q4 *)d.d_tris; v.spheres = (const Sphere *)d.d_spheres;
@@ -837,9 +849,7 @@ static int acquire_scratch(DeviceScene &d, hipStream_t stream, uint32_t chunks, 
         HIP_TRY(hipEventCreate(&x->ev0));
         HIP_TRY(hipEventCreate(&x->ev1));
         HIP_TRY(hipEventCreate(&x->ev_done));
-        HIP_TRY(hipStreamCreateWithFlags(&x->split.helper, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&x->split.fork, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&x->split.join, hipEventDisableTiming));
+        HIP_TRY(make_split_streams(x->split, std::getenv("CRT_SPLIT_OWN_HELPER") ? nullptr : d.noalloc_split.helper));
     }
     if (chunks > 1) {
         const size_t need = chunk_slab_floats(rgb_floats, chunks);

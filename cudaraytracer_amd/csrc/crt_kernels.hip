@@ -9,6 +9,7 @@
 // to a workgroup without it.  The traversal stack is an LDS column per lane (stack[level][lane]: bank = lane, conflict
 // free).
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <mutex>
 
@@ -297,19 +298,24 @@ static_assert(CRT_WORK_STRIPES == 64u, "the order in which a wave visits the blo
 #else
 #define CRT_OCCUPANCY_ATTR
 #endif
-template <bool COUNT_WORK, int SD, bool SS, int W, int NC>
-__global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
-                                                                       int *__restrict__ ids, unsigned long long *__restrict__ counters)
+extern __shared__ int lds_stack_dynamic[]; // render_kernel_large's stacks (see there)
+template <bool COUNT_WORK, int SD, bool SS, int W, int NC, bool DYNAMIC_STACK = false>
+__device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *__restrict__ out,
+                                            int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
     // W waves per workgroup, each on its own; with NC > 0 they share an LDS copy of the first NC nodes (breadth-first
     // numbering: the top of the tree).  The kernel is limited by the CU's address unit as much as by VALU issue (one more
     // dwordx4 load per node step costs 13 % of the frame), and about 70 % of the node visits of the headline scene go to the
     // first ~240 nodes: those are read from LDS.  W = 4, NC = 236, SD = 16: 4 x 4.5 KB of stack + 13 KB of nodes = 31.6 KB,
     // five workgroups per CU = the same 20 waves as with one wave per workgroup.
-    __shared__ int lds_stack_all[W][(SD + 2) * 64]; // SD = 16 when the BVH is at most 16 levels deep
     __shared__ float lds_nodes[NC > 0 ? CRT_LDS_NODE_WORDS * NC : 1];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    int *lds_stack = lds_stack_all[wave];
+    int *lds_stack;
+    if constexpr (DYNAMIC_STACK) lds_stack = lds_stack_dynamic + wave * ((SD + 2) * 64);
+    else {
+        __shared__ int lds_stack_all[W][(SD + 2) * 64]; // SD = 16 when the BVH is at most 16 levels deep
+        lds_stack = lds_stack_all[wave];
+    }
     CachedNodes node_src;
     node_src.global = sc.nodes; node_src.lds = (lds_q4_ptr)lds_nodes; node_src.ncached = NC > 0 ? min((int)sc.nnodes, NC) : 0;
     if (NC > 0) {
@@ -622,6 +628,28 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
             for (int k = 0; k < 9; k++) atomicAdd(&counters[18 + k], clk.sum[k]); // section clocks (CRT_PRINT_SECTIONS)
         }
     }
+}
+
+template <bool COUNT_WORK, int SD, bool SS, int W, int NC>
+__global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
+                                                                       int *__restrict__ ids, unsigned long long *__restrict__ counters)
+{
+    render_body<COUNT_WORK, SD, SS, W, NC>(sc, cam, ra, out, ids, counters);
+}
+
+// The 16-wave workgroup of a two-launch frame (launch_split).  With all of its LDS declared (one workgroup per CU) the compiler
+// assumes four waves per SIMD and hands out up to 128 registers whatever the attributes say; the kernel takes 99-101, is allocated
+// 104, and beside the small workgroup's 96 that is all 512 registers of a SIMD lane: nothing else gets onto the CU while a frame
+// is resident, and the 21-register finalize pass of the PREVIOUS frame -- which the next frame on its stream waits for -- only
+// runs when the frame drains.  So the stacks (addressed through a per-lane pointer anyway) are dynamic LDS, whose size the
+// compiler does not see, the five-waves-per-SIMD attribute holds the kernel to 96 registers, and the pair leaves the same 32
+// registers per SIMD lane free as five 96-register waves do.
+template <int SD> constexpr size_t large_stack_bytes() { return (size_t)16 * (SD + 2) * 64 * sizeof(int); }
+template <bool COUNT_WORK, int SD, bool SS, int NC>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(CRT_WAVES_PER_EU, CRT_WAVES_PER_EU)))
+void render_kernel_large(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out, int *__restrict__ ids, unsigned long long *__restrict__ counters)
+{
+    render_body<COUNT_WORK, SD, SS, 16, NC, true>(sc, cam, ra, out, ids, counters);
 }
 
 // =========================================================================================================
@@ -1156,7 +1184,16 @@ static bool launch_split(const SceneView &sc, const CameraPOD &cam, const Render
         const uint32_t cus = (blocks + 19u) / 20u; // blocks = persistent waves, 20 per CU
         // the small workgroups start behind whatever the caller's stream holds, the caller's stream goes on behind them
         if (hipEventRecord(split->fork, stream) != hipSuccess || hipStreamWaitEvent(split->helper, split->fork, 0) != hipSuccess) return false;
-        hipLaunchKernelGGL((render_kernel<CW, SD, SS, 16, NA>), dim3(cus), dim3(1024), 0, stream, sc, cam, a, out, ids, counters);
+        // (64-104 KB of dynamic LDS: allowed explicitly, once per device the kernel is launched on)
+        static std::atomic<uint64_t> allowed{ 0 };
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        if (dev < 64 && !(allowed.load(std::memory_order_relaxed) >> dev & 1u)) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel_large<CW, SD, SS, NA>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)large_stack_bytes<SD>()) != hipSuccess) { (void)hipGetLastError(); return false; }
+            allowed.fetch_or(1ull << dev, std::memory_order_relaxed);
+        }
+        hipLaunchKernelGGL((render_kernel_large<CW, SD, SS, NA>), dim3(cus), dim3(1024), large_stack_bytes<SD>(), stream, sc, cam, a, out, ids, counters);
         hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, NB>), dim3(cus), dim3(256), 0, split->helper, sc, cam, a, out, ids, counters);
         if (hipEventRecord(split->join, split->helper) != hipSuccess || hipStreamWaitEvent(stream, split->join, 0) != hipSuccess) return false;
         return true;
@@ -1202,11 +1239,22 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     // blocks mean fewer trips, smaller ones a more even end of the frame; measured at one sample per unit (headline frame,
     // tools/fetch_block_sweep.py, ms per frame at 128 / 256 / 512 / 1024): whole frame 9.56 / 9.46 / 9.42 / 9.49, 1/2 of it
     // 4.86 / 4.79 / 4.79 / 4.86, 1/4 2.46 / 2.42 / 2.42 / 2.49, 1/8 1.267 / 1.254 / 1.268 / 1.34.  Rule: a resident wave
-    // makes at least 8 trips per frame, blocks of 64..512 units.
+    // makes at least 8 trips per frame, blocks of 64..512 units.  The two-launch frame (16 + 4 split, below) wants at most 128: its
+    // 16-wave workgroups only leave a CU when all sixteen waves have run out of work (same sweep, 64 / 128 / 256 / 512: whole
+    // frame 8.60 / 8.37 / 8.39 / 8.61, 1/2 4.42 / 4.30 / 4.39 / 4.52, 1/4 2.31 / 2.29 / 2.31 / 2.56, 1/8 1.28 / 1.27 / 1.34 / 1.49;
+    // the 1 M-triangle grid 36.9 at 512, 36.7 at 128; cats 4K x 1024 spp 504.7 / 503.6).
+    const uint64_t units = (uint64_t)local_tiles * a.chunks; // wave-sized work units
+    const uint32_t blocks = units < max_waves ? (uint32_t)units : max_waves;
+    // node_cache = 1, chosen by the frame: one that does not fill the GPU spreads better as single waves (0); one that fills it many
+    // times over takes the 16 + 4 split where the tree allows it (4: the large workgroups' LDS copies and their 16 waves that
+    // must all finish before the slot is free only pay on long frames); else four-wave workgroups (2)
+    if (a.node_cache == 1) a.node_cache = units < max_waves ? 0u : (units >= 8ull * max_waves && split && split->helper && ra.bvh_depth <= 24 && blocks == max_waves) ? 4u : 2u;
+    if (a.node_cache == 4 && !(split && split->helper && ra.bvh_depth <= 24)) a.node_cache = 2; // (asked for by name: small frames too, the tests do)
     if (a.fetch_shift == 0) {
         const uint64_t per_wave = (uint64_t)local_tiles * 64u * a.chunks / (max_waves ? max_waves : 1u);
+        const uint32_t top = a.node_cache == 4 ? 7u : 9u;
         a.fetch_shift = 6;
-        while (a.fetch_shift < 9 && (16ull << a.fetch_shift) <= per_wave) a.fetch_shift++;
+        while (a.fetch_shift < top && (16ull << a.fetch_shift) <= per_wave) a.fetch_shift++;
     }
     if (a.fetch_shift < 6) a.fetch_shift = 6;
     if (a.fetch_shift > 16) a.fetch_shift = 16;
@@ -1215,9 +1263,7 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
         a.blocks_per_stripe = (uint32_t)((nblocks + CRT_WORK_STRIPES - 1) / CRT_WORK_STRIPES);
     }
     a.tiles_x_magic = a.tiles_x > 1 ? (uint32_t)((1ull << 32) / a.tiles_x) : 0xFFFFFFFFu; // tiles_x == 1: tile / 1 = tile - (0 or 1), fixed up
-    // persistent waves: enough to fill the device; each lane keeps drawing pixels until the counter runs out
-    const uint64_t units = (uint64_t)local_tiles * a.chunks; // wave-sized work units
-    const uint32_t blocks = units < max_waves ? (uint32_t)units : max_waves;
+    // persistent waves (blocks, above): enough to fill the device; each lane keeps drawing pixels until the counter runs out
     if (ra.kernel == RK_POOL && a.chunks == 1) { // (the pool kernel has no sample chunks)
         // Experimental (CRT_KERNEL=1).  One wave per workgroup, 96 contexts, no LDS node cache: the variant that measured
         // best (8 waves sharing an LDS copy of the whole node array ran slower, 1.75 waves per SIMD
@@ -1233,11 +1279,6 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     // the LDS stack is sized by the tree: 14 levels (4 KB per wave), 16 (4.5 KB), 24 (6.5 KB: still the 20 waves per CU the registers
     // allow) or 32 (8.5 KB: 18 waves per CU)
     const bool ss = sc.sphere_slots != 0;
-    // node_cache = 1, chosen by the frame: one that does not fill the GPU spreads better as single waves (0); one that fills it many
-    // times over takes the 16 + 4 split where the tree allows it (4: the large workgroups' LDS copies and their 16 waves that
-    // must all finish before the slot is free only pay on long frames); else four-wave workgroups (2)
-    if (a.node_cache == 1) a.node_cache = units < max_waves ? 0u : (units >= 8ull * max_waves && split && split->helper && ra.bvh_depth <= 24 && blocks == max_waves) ? 4u : 2u;
-    if (a.node_cache == 4 && !(split && split->helper && ra.bvh_depth <= 24)) a.node_cache = 2; // (asked for by name: small frames too, the tests do)
     // (the whole-tree variant exists for the 16-level stack only)
     const int levels = (ra.bvh_depth <= 14 && a.node_cache != 3) ? 14 : ra.bvh_depth <= 16 ? 16 : ra.bvh_depth <= 24 ? 24 : CRT_STACK_DEPTH;
 #define CRT_LAUNCH_SS(CW, SD) do { if (ss) launch_lanes<CW, SD, true>(sc, cam, a, out, ids, counters, blocks, stream, split); \

@@ -4,5 +4,5 @@
 ROUNDS=${2:-2}
 IFS='|' read -ra SETS <<< "$1"
 for R in $(seq 1 $ROUNDS); do for E in "${SETS[@]}"; do
-  env $E timeout -k 10 120 python -u bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('round $R [$E]', round(d['value']), 'Mrays/s', round(d['ms_per_step'],2), 'ms')"
+  env $E timeout -k 10 120 python -u bench.py --steps ${STEPS:-3} --warmup 2 --no-cpu-baseline ${BENCH_ARGS:-} 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('round $R [$E]', round(d['value']), 'Mrays/s', round(d['ms_per_step'],2), 'ms')"
 done; done

@@ -27,5 +27,5 @@ for rep in range(2):
         for fb in blocks:
             os.environ["CRT_FETCH_BLOCK"] = str(fb)
             s.reload_tuning()
-            row.append("%d: %.3f" % (fb, timed(N, 2 if N < 4 else 3)))
+            row.append("%d: %.3f" % (fb, timed(N, 2)))
         print("ranks %d, chunks %d, ms per rank-frame by block size  " % (N, chunks) + "   ".join(row), flush=True)

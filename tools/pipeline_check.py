@@ -18,7 +18,7 @@ _, cam = scenes.make_camera(W)
 CASES = (("two in flight, no collective", dict(pipelined=True)), ("three in flight, all-gather + untile", dict(pipelined=3, force_collective=True)), ("two in flight, all-gather + untile", dict(pipelined=True, force_collective=True)),
                  ("one at a time, all-gather + untile", dict(pipelined=False, force_collective=True)), ("one at a time, no collective", dict(pipelined=False)))
 for name, kw in CASES + CASES[::-1]:   # every case twice, in both orders: the first case also pays RCCL's first-use set-up
-    f = TileFrame(W, H, 1, 0, dev, sample_chunks=32, **kw)
+    f = TileFrame(W, H, 1, 0, dev, sample_chunks=64, **kw)
     for _ in range(4):
         f.render_local(s, cam, spp, 10, 1984); f.gather_async()
     f.drain(); torch.cuda.synchronize()
