@@ -1184,16 +1184,21 @@ static bool launch_split(const SceneView &sc, const CameraPOD &cam, const Render
         const uint32_t cus = (blocks + 19u) / 20u; // blocks = persistent waves, 20 per CU
         // the small workgroups start behind whatever the caller's stream holds, the caller's stream goes on behind them
         if (hipEventRecord(split->fork, stream) != hipSuccess || hipStreamWaitEvent(split->helper, split->fork, 0) != hipSuccess) return false;
-        // (64-104 KB of dynamic LDS: allowed explicitly, once per device the kernel is launched on)
-        static std::atomic<uint64_t> allowed{ 0 };
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return false;
-        if (dev < 64 && !(allowed.load(std::memory_order_relaxed) >> dev & 1u)) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel_large<CW, SD, SS, NA>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)large_stack_bytes<SD>()) != hipSuccess) { (void)hipGetLastError(); return false; }
-            allowed.fetch_or(1ull << dev, std::memory_order_relaxed);
+        if constexpr (CW) {
+            // (the instrumented variant needs more registers than 96: it keeps the form with all of its LDS declared, 104-128 registers)
+            hipLaunchKernelGGL((render_kernel<CW, SD, SS, 16, NA>), dim3(cus), dim3(1024), 0, stream, sc, cam, a, out, ids, counters);
+        } else {
+            // (64-104 KB of dynamic LDS: allowed explicitly, once per device the kernel is launched on)
+            static std::atomic<uint64_t> allowed{ 0 };
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess) return false;
+            if (dev < 64 && !(allowed.load(std::memory_order_relaxed) >> dev & 1u)) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel_large<CW, SD, SS, NA>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)large_stack_bytes<SD>()) != hipSuccess) { (void)hipGetLastError(); return false; }
+                allowed.fetch_or(1ull << dev, std::memory_order_relaxed);
+            }
+            hipLaunchKernelGGL((render_kernel_large<CW, SD, SS, NA>), dim3(cus), dim3(1024), large_stack_bytes<SD>(), stream, sc, cam, a, out, ids, counters);
         }
-        hipLaunchKernelGGL((render_kernel_large<CW, SD, SS, NA>), dim3(cus), dim3(1024), large_stack_bytes<SD>(), stream, sc, cam, a, out, ids, counters);
         hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, NB>), dim3(cus), dim3(256), 0, split->helper, sc, cam, a, out, ids, counters);
         if (hipEventRecord(split->join, split->helper) != hipSuccess || hipStreamWaitEvent(stream, split->join, 0) != hipSuccess) return false;
         return true;

@@ -3,8 +3,9 @@ of the per-FRAME PMC figures of render_kernel<false> with the derived figures DE
 
 A frame that fills the GPU runs as two render kernels at once (the 16 + 4 split): rocprofv3 serialises
 dispatches while it collects counters, so in the PMC passes whichever of the two starts first does the whole frame and the other
-finds the work queue empty.  Counters are therefore summed over both kernels of a frame (instruction, lane and byte counts do
-not depend on which kernel did the work); the frame's duration comes from the kernel trace, where the two run together
+finds the work queue empty.  Counters are therefore summed over both kernels of a frame, and the figures quoted are the mean of
+the frames that the LARGE kernel rendered (it has 4/5 of the waves in a normal run; the frames that the small kernel rendered --
+more node steps from device memory -- are kept beside them as frames_rendered_by_the_small_kernel); the frame's duration comes from the kernel trace, where the two run together
 (first start to last end), and the shader clock from the PMC pass's own GRBM_GUI_ACTIVE and timestamps."""
 import collections
 import csv
@@ -19,24 +20,38 @@ shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(d
 out = {}
 for f in ["pmc_sq1", "pmc_sq2", "pmc_tcc1", "pmc_tcc2"]:
     rows = list(csv.DictReader(open(os.path.join(src, f, f + "_counter_collection.csv"))))
-    agg = collections.defaultdict(float)
-    per_name = collections.defaultdict(set)
-    spans = {}
+    # dispatches of the render kernels in start order; with two kernels per frame, consecutive pairs are frames
+    disp_rows = collections.OrderedDict()
     for r in rows:
-        if "kernel<false" in r["Kernel_Name"]:
-            agg[r["Counter_Name"]] += float(r["Counter_Value"])
-            per_name[r["Kernel_Name"]].add(r["Dispatch_Id"])
-            spans[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+        if "kernel<false" in r["Kernel_Name"] or "kernel_large<false" in r["Kernel_Name"]:
+            d = disp_rows.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"], "start": int(r["Start_Timestamp"]), "end": int(r["End_Timestamp"]), "c": {}})
+            d["c"][r["Counter_Name"]] = d["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             out.setdefault("kernels", {})[r["Kernel_Name"].split("(")[0]] = {"LDS_Block_Size": r["LDS_Block_Size"], "Scratch_Size": r["Scratch_Size"],
                                                                           "Grid_Size": r["Grid_Size"], "VGPR_Count": r["VGPR_Count"]}
-    frames = max(len(v) for v in per_name.values())
-    for k, v in agg.items():
-        out[k] = v / frames
-    if "GRBM_GUI_ACTIVE" in agg:
-        out["pmc_pass_ns_per_frame"] = sum(spans.values()) / frames
+    ds = sorted(disp_rows.values(), key=lambda d: d["start"])
+    per_frame = 2 if len(set(d["name"] for d in ds)) == 2 else 1
+    frames_p = [ds[k:k + per_frame] for k in range(0, len(ds), per_frame)]
+    # which kernel rendered the frame (the PMC passes serialise the two): the one that ran longer
+    kinds = collections.defaultdict(list)
+    for fr in frames_p:
+        worker = max(fr, key=lambda d: d["end"] - d["start"])
+        kinds["large_kernel_first" if "large" in worker["name"] or per_frame == 1 else "small_kernel_first"].append(fr)
+    main = kinds["large_kernel_first"] or kinds["small_kernel_first"]
+    def mean(frs, key):
+        return sum(sum(d["c"].get(key, 0.0) for d in fr) for fr in frs) / len(frs)
+    names = sorted(set(k for d in ds for k in d["c"]))
+    for k in names:
+        out[k] = mean(main, k)
+    if kinds["small_kernel_first"] and kinds["large_kernel_first"]:
+        o2 = out.setdefault("frames_rendered_by_the_small_kernel", {})
+        for k in names:
+            o2[k] = mean(kinds["small_kernel_first"], k)
+    out.setdefault("pmc_frames", {})[f] = {k: len(v) for k, v in kinds.items()}
+    if "GRBM_GUI_ACTIVE" in names:
+        out["pmc_pass_ns_per_frame"] = sum(sum(d["end"] - d["start"] for d in fr) for fr in main) / len(main)
 # the frame's duration where its kernels run together: the kernel trace, first start to last end of each frame
 disp = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in
-               csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_trace.csv"))) if "kernel<false" in r["Kernel_Name"]))
+               csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_trace.csv"))) if "kernel<false" in r["Kernel_Name"] or "kernel_large<false" in r["Kernel_Name"]))
 frames_t = []
 for s0, e0, name in disp:
     if frames_t and s0 < frames_t[-1][1] and name not in frames_t[-1][2]:
