@@ -21,6 +21,7 @@ namespace crt {
 // Per-lane traversal stack: an LDS column (stack[level][lane]: bank = lane, conflict free).  Level 0 holds the
 // CRT_BVH_NONE sentinel for the whole kernel, so pop() needs no empty check: popping it ends the walk.
 struct LdsStack {
+    typedef int entry;
     int *top; // next free slot of this lane's column (stride 64 ints)
     int *base;
     __device__ __forceinline__ void init(int *column) { column[0] = CRT_BVH_NONE; base = column + 64; top = base; }
@@ -33,12 +34,30 @@ struct LdsStack {
     __device__ __forceinline__ void pop_if(bool c) { top -= c ? 64 : 0; }
 };
 
+// The same column with 16-bit entries, for trees whose every reference fits a short (fewer than 32767 nodes, at most 4096
+// triangle slots: leaf references are ~((first << 3) | (count - 1)) >= -32768): half the LDS per wave, which the copy of the top
+// of the tree gets.  The end-of-walk value is 0x7FFF here (it must survive the trip through a short), and so it is for the
+// whole kernel that uses this stack: stack_none<> below, used wherever the 32-bit kernels say CRT_BVH_NONE.
+struct LdsStack16 {
+    typedef short entry;
+    short *top, *base;
+    __device__ __forceinline__ void init(short *column) { column[0] = (short)0x7FFF; base = column + 64; top = base; }
+    __device__ __forceinline__ void reset() { top = base; }
+    __device__ __forceinline__ void push(int v) { *top = (short)v; top += 64; }
+    __device__ __forceinline__ int pop() { top -= 64; return *top; }
+    __device__ __forceinline__ int peek() { return *(top - 64); }
+    __device__ __forceinline__ void push_if(int v, bool c) { *top = (short)v; top += c ? 64 : 0; }
+    __device__ __forceinline__ void pop_if(bool c) { top -= c ? 64 : 0; }
+};
+template <> struct stack_none<LdsStack16> { static constexpr int value = 0x7FFF; };
+
 // The same stack with its top entry in a lane register (BASELINE.json's "short stack in VGPRs spilling to LDS", one entry
 // deep): peek() costs nothing, but the branch-free node step must still read what a pop would uncover (now the second
 // entry) and store what a push covers (now the old top), so the LDS traffic per step is the same one read and one write,
 // and two more selects keep the register current.  Measured with -DCRT_REG_TOS=1: slower; kept for
 // the record, not used.
 struct RegTopStack {
+    typedef int entry;
     int *top;  // next free LDS slot of this lane's column: entries [base, top) lie below `tos`
     int *base;
     int tos;   // the top entry
@@ -310,10 +329,14 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
     // five workgroups per CU = the same 20 waves as with one wave per workgroup.
     __shared__ float lds_nodes[NC > 0 ? CRT_LDS_NODE_WORDS * NC : 1];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // SD = 14: trees at most 14 levels deep whose references fit 16 bits (launch_render checks both)
+    typedef typename std::conditional<CRT_REG_TOS != 0, RegTopStack, typename std::conditional<SD == 14, LdsStack16, LdsStack>::type>::type stack_t;
+    constexpr int NONE = stack_none<stack_t>::value;
+    constexpr int STACK_INTS = (SD + 2) * 64 * (int)sizeof(typename stack_t::entry) / 4; // per wave
     int *lds_stack;
-    if constexpr (DYNAMIC_STACK) lds_stack = lds_stack_dynamic + wave * ((SD + 2) * 64);
+    if constexpr (DYNAMIC_STACK) lds_stack = lds_stack_dynamic + wave * STACK_INTS;
     else {
-        __shared__ int lds_stack_all[W][(SD + 2) * 64]; // SD = 16 when the BVH is at most 16 levels deep
+        __shared__ int lds_stack_all[W][STACK_INTS];
         lds_stack = lds_stack_all[wave];
     }
     CachedNodes node_src;
@@ -334,8 +357,8 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
     const uint32_t NO_PIXEL = 0xFFFFFFFFu;
     const float tmin = 0.001f; // camera.h:68
 
-    typename std::conditional<CRT_REG_TOS != 0, RegTopStack, LdsStack>::type stack;
-    stack.init(lds_stack + lane);
+    stack_t stack;
+    stack.init(reinterpret_cast<typename stack_t::entry *>(lds_stack) + lane);
     typename std::conditional<COUNT_WORK, RegCounters<SS>, RayCounters<SS>>::type cnt;
     cnt.refold_counter = counters + 4;
 
@@ -352,7 +375,7 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
     Search hit;
     hit.t = FLT_MAX; hit.code = -1; hit.mat = 0; hit.rank = 0; hit.near_tie = false;
     Trav tv;
-    tv.idir = tv.ood = mk3(0.0f, 0.0f, 0.0f); tv.shift = 0.0f; tv.hi = 0.0f; tv.cur = CRT_BVH_NONE;
+    tv.idir = tv.ood = mk3(0.0f, 0.0f, 0.0f); tv.shift = 0.0f; tv.hi = 0.0f; tv.cur = NONE;
     const int threshold = (int)ra.sched_threshold;
     uint32_t wc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // schedule counters, lane 0 only (COUNT_WORK)
     unsigned long long t_start = 0;
@@ -365,7 +388,7 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
     // host reports (counters[CRT_COUNTER_GUARD], checked by crt_render) instead of a wave that never leaves the GPU.
     bool guard_tripped = false;
     for (uint32_t guard = 0;; guard++) {
-        const bool walking = tv.cur != CRT_BVH_NONE;
+        const bool walking = tv.cur != NONE;
         // (every lane is alive here, so masks of single comparisons can be combined as scalars; a ballot of `a && b` would
         // first write the bool to a register and compare it again)
         const unsigned long long walk_mask = __ballot(walking), active_mask = ~walk_mask & __ballot(phase != P_DONE);
@@ -550,7 +573,7 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
             // ================================ phase B ================================
             const int alive = nready + nwalk;
             for (;;) {
-                const bool inner = is_inner(tv.cur), leaf = tv.cur < 0;
+                const bool inner = is_inner<NONE>(tv.cur), leaf = tv.cur < 0;
                 const int n_inner = popc64(__ballot(inner)), n_leaf = popc64(__ballot(leaf));
                 const int nw = n_inner + n_leaf;
                 if (nw == 0 || alive - nw >= threshold) break;
@@ -584,7 +607,7 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
                     // more node steps on the same vote: descents come in runs, and the vote costs half a step in scalar work
 #pragma unroll
                     for (int k = 1; k < CRT_NODE_STEPS_PER_VOTE; k++) {
-                        const bool again = mine && is_inner(tv.cur);
+                        const bool again = mine && is_inner<NONE>(tv.cur);
                         if constexpr (COUNT_WORK) { const int na = popc64(__ballot(again)); if (lane == 0) { wc[4]++; wc[5] += na; } }
                         if (again) trav_inner(sc, tv, stack, cnt);
                     }
@@ -644,7 +667,7 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
 // runs when the frame drains.  So the stacks (addressed through a per-lane pointer anyway) are dynamic LDS, whose size the
 // compiler does not see, the five-waves-per-SIMD attribute holds the kernel to 96 registers, and the pair leaves the same 32
 // registers per SIMD lane free as five 96-register waves do.
-template <int SD> constexpr size_t large_stack_bytes() { return (size_t)16 * (SD + 2) * 64 * sizeof(int); }
+template <int SD> constexpr size_t large_stack_bytes() { return (size_t)16 * (SD + 2) * 64 * (SD == 14 ? sizeof(short) : sizeof(int)); } // (14 levels: 16-bit entries)
 template <bool COUNT_WORK, int SD, bool SS, int NC>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(CRT_WAVES_PER_EU, CRT_WAVES_PER_EU)))
 void render_kernel_large(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out, int *__restrict__ ids, unsigned long long *__restrict__ counters)
@@ -1167,8 +1190,9 @@ static bool launch_whole_tree(const SceneView &sc, const CameraPOD &cam, const R
 // same kernel with other template arguments, so the frame is the same bit for bit.  The small copy must stay below 32 KB per
 // workgroup: above it the compiler sees an LDS-limited occupancy of 4 waves per SIMD, gives the kernel 128 registers, and the
 // workgroup no longer fits beside the large one (16 ms).
-#define CRT_SPLIT_A_NODES_14 1328 // 16 x 4 KB   of stack + 1328 x 56 B = 136.6 KB
-#define CRT_SPLIT_B_NODES_14 112  //  4 x 4 KB   of stack +  112 x 56 B =  22.1 KB
+#define CRT_NODE_CACHE_NODES_14 418 // 4 x 2 KB of stack (16-bit entries) + 418 x 56 B = 30.9 KB
+#define CRT_SPLIT_A_NODES_14 1328 // 16 x 2 KB   of stack + 1328 x 56 B = 104.6 KB (16-bit stack entries)
+#define CRT_SPLIT_B_NODES_14 CRT_NODE_CACHE_NODES_14 // 4 x 2 KB of stack + 418 x 56 B = 30.9 KB: the five-workgroup form's kernel
 #define CRT_SPLIT_A_NODES_16 1176 // 16 x 4.5 KB of stack + 1176 x 56 B = 136.3 KB
 #define CRT_SPLIT_B_NODES_16 76   //  4 x 4.5 KB of stack +   76 x 56 B =  22.2 KB
 #define CRT_SPLIT_A_NODES_24 508  // 16 x 6.5 KB of stack +  508 x 56 B = 131.8 KB
@@ -1209,7 +1233,6 @@ static bool launch_split(const SceneView &sc, const CameraPOD &cam, const Render
 // The lane kernel for a stack of SD levels: four waves per workgroup sharing an LDS copy of the top of the tree where the LDS
 // has room for one beside five workgroups' stacks (SD = 14: 272 nodes, 16: 236, 24: 88), else single waves.
 // (if constexpr: only the combinations that can be launched are instantiated)
-#define CRT_NODE_CACHE_NODES_14 272 // 4 x 4 KB of stack + 272 x 56 B = 31.6 KB
 #ifndef CRT_NODE_CACHE_NODES_24
 #define CRT_NODE_CACHE_NODES_24 88  // 4 x 6.5 KB of stack + 88 x 56 B = 31.6 KB
 #endif
@@ -1285,7 +1308,9 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     // allow) or 32 (8.5 KB: 18 waves per CU)
     const bool ss = sc.sphere_slots != 0;
     // (the whole-tree variant exists for the 16-level stack only)
-    const int levels = (ra.bvh_depth <= 14 && a.node_cache != 3) ? 14 : ra.bvh_depth <= 16 ? 16 : ra.bvh_depth <= 24 ? 24 : CRT_STACK_DEPTH;
+    // (14 levels: the kernels with 16-bit stack entries, for trees whose references fit a short -- LdsStack16)
+    const bool short_refs = sc.nnodes < 32767u && sc.ntris <= 4096u;
+    const int levels = (ra.bvh_depth <= 14 && short_refs && a.node_cache != 3) ? 14 : ra.bvh_depth <= 16 ? 16 : ra.bvh_depth <= 24 ? 24 : CRT_STACK_DEPTH;
 #define CRT_LAUNCH_SS(CW, SD) do { if (ss) launch_lanes<CW, SD, true>(sc, cam, a, out, ids, counters, blocks, stream, split); \
                                    else launch_lanes<CW, SD, false>(sc, cam, a, out, ids, counters, blocks, stream, split); } while (0)
 #define CRT_LAUNCH_SD(CW) do { if (levels == 14) CRT_LAUNCH_SS(CW, 14); else if (levels == 16) CRT_LAUNCH_SS(CW, 16); else if (levels == 24) CRT_LAUNCH_SS(CW, 24); \

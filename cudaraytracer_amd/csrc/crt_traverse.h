@@ -165,7 +165,11 @@ CRT_HD T load_global(const T *p, size_t k)
 #endif
 }
 
-CRT_HD bool is_inner(int ref) { return (unsigned)ref < (unsigned)CRT_BVH_NONE; }
+// The end-of-walk value of a stack type: CRT_BVH_NONE, or a smaller one where the stack's entries are narrower than an int
+// (crt_kernels.hip: the 16-bit stack of small trees; every reference of such a tree lies below it).
+template <class Stack> struct stack_none { static constexpr int value = CRT_BVH_NONE; };
+template <int NONE = CRT_BVH_NONE>
+CRT_HD bool is_inner(int ref) { return (unsigned)ref < (unsigned)NONE; }
 
 // Spheres: a short flat list (ground + light in the reference scenes, scene.h:164-165), tested before the BVH.
 // MODE_CLOSEST: s.t must start at tmax (FLT_MAX).  MODE_NEXT_RANK: only candidates with t <= t_hi and
@@ -183,10 +187,10 @@ CRT_HD void trav_spheres(const SceneView &sc, f3 o, f3 d, float tmin, Search &s,
 
 // Root box of the triangle BVH against the current best t: sets up the slab registers.  Leaves
 // tv.cur = CRT_BVH_NONE if no node needs visiting.
-template <int MODE>
+template <int MODE, int NONE = CRT_BVH_NONE>
 CRT_HD void trav_root(const SceneView &sc, f3 o, f3 d, const Search &s, float t_hi, Trav &tv)
 {
-    tv.cur = CRT_BVH_NONE;
+    tv.cur = NONE;
     if (sc.root_ref == CRT_BVH_NONE) return;
     // slab arithmetic for pruning: idir finite, origin re-based to the root box entry so that rounding stays
     // small against the box margin wherever the ray starts.
@@ -211,7 +215,7 @@ template <int MODE, class Stack, class Counters>
 CRT_HD void trav_begin(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Trav &tv, Stack &stack, Counters &cnt)
 {
     trav_spheres<MODE>(sc, o, d, tmin, s, after_rank, t_hi, cnt);
-    trav_root<MODE>(sc, o, d, s, t_hi, tv);
+    trav_root<MODE, stack_none<Stack>::value>(sc, o, d, s, t_hi, tv);
     stack.reset();
 }
 
@@ -318,8 +322,8 @@ template <int MODE, class Stack, class Counters>
 CRT_HD void walk(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Stack &stack, Counters &cnt, Trav &tv)
 {
     trav_begin<MODE>(sc, o, d, tmin, s, after_rank, t_hi, tv, stack, cnt);
-    while (tv.cur != CRT_BVH_NONE) {
-        while (is_inner(tv.cur)) trav_inner(sc, tv, stack, cnt);
+    while (tv.cur != stack_none<Stack>::value) {
+        while (is_inner<stack_none<Stack>::value>(tv.cur)) trav_inner(sc, tv, stack, cnt);
         if (tv.cur < 0) trav_leaf<MODE>(sc, o, d, tmin, s, after_rank, t_hi, tv, stack, cnt);
     }
 }
