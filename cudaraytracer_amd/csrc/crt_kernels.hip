@@ -317,8 +317,8 @@ static_assert(CRT_WORK_STRIPES == 64u, "the order in which a wave visits the blo
 #else
 #define CRT_OCCUPANCY_ATTR
 #endif
-extern __shared__ int lds_stack_dynamic[]; // render_kernel_large's stacks (see there)
-template <bool COUNT_WORK, int SD, bool SS, int W, int NC, bool DYNAMIC_STACK = false>
+extern __shared__ int lds_dynamic[]; // render_kernel_dyn's stacks (DYNAMIC = 1) or node copy + stacks (DYNAMIC = 2), see there
+template <bool COUNT_WORK, int SD, bool SS, int W, int NC, int DYNAMIC = 0>
 __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *__restrict__ out,
                                             int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
@@ -327,14 +327,19 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
     // dwordx4 load per node step costs 13 % of the frame), and about 70 % of the node visits of the headline scene go to the
     // first ~240 nodes: those are read from LDS.  W = 4, NC = 236, SD = 16: 4 x 4.5 KB of stack + 13 KB of nodes = 31.6 KB,
     // five workgroups per CU = the same 20 waves as with one wave per workgroup.
-    __shared__ float lds_nodes[NC > 0 ? CRT_LDS_NODE_WORDS * NC : 1];
+    float *lds_nodes;
+    if constexpr (DYNAMIC == 2) lds_nodes = reinterpret_cast<float *>(lds_dynamic);
+    else {
+        __shared__ float lds_nodes_static[NC > 0 ? CRT_LDS_NODE_WORDS * NC : 1];
+        lds_nodes = lds_nodes_static;
+    }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     // SD = 14: trees at most 14 levels deep whose references fit 16 bits (launch_render checks both)
     typedef typename std::conditional<CRT_REG_TOS != 0, RegTopStack, typename std::conditional<SD == 14, LdsStack16, LdsStack>::type>::type stack_t;
     constexpr int NONE = stack_none<stack_t>::value;
     constexpr int STACK_INTS = (SD + 2) * 64 * (int)sizeof(typename stack_t::entry) / 4; // per wave
     int *lds_stack;
-    if constexpr (DYNAMIC_STACK) lds_stack = lds_stack_dynamic + wave * STACK_INTS;
+    if constexpr (DYNAMIC != 0) lds_stack = lds_dynamic + (DYNAMIC == 2 ? CRT_LDS_NODE_WORDS * NC : 0) + wave * STACK_INTS;
     else {
         __shared__ int lds_stack_all[W][STACK_INTS];
         lds_stack = lds_stack_all[wave];
@@ -665,14 +670,19 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
 // 104, and beside the small workgroup's 96 that is all 512 registers of a SIMD lane: nothing else gets onto the CU while a frame
 // is resident, and the 21-register finalize pass of the PREVIOUS frame -- which the next frame on its stream waits for -- only
 // runs when the frame drains.  So the stacks (addressed through a per-lane pointer anyway) are dynamic LDS, whose size the
-// compiler does not see, the five-waves-per-SIMD attribute holds the kernel to 96 registers, and the pair leaves the same 32
-// registers per SIMD lane free as five 96-register waves do.
-template <int SD> constexpr size_t large_stack_bytes() { return (size_t)16 * (SD + 2) * 64 * (SD == 14 ? sizeof(short) : sizeof(int)); } // (14 levels: 16-bit entries)
-template <bool COUNT_WORK, int SD, bool SS, int NC>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(CRT_WAVES_PER_EU, CRT_WAVES_PER_EU)))
-void render_kernel_large(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out, int *__restrict__ ids, unsigned long long *__restrict__ counters)
+// compiler does not see (DYNAMIC = 1), the five-waves-per-SIMD attribute holds the kernel to 96 registers, and the pair leaves
+// the same 32 registers per SIMD lane free as five 96-register waves do.  The small workgroup of the pair has the same problem
+// from 32 KB of LDS on (four waves per SIMD by LDS -> 128 registers): with node copy AND stacks dynamic (DYNAMIC = 2) it can use
+// whatever the large one leaves.
+template <int SD, int W, int NC, int DYNAMIC> constexpr size_t dynamic_lds_bytes()
 {
-    render_body<COUNT_WORK, SD, SS, 16, NC, true>(sc, cam, ra, out, ids, counters);
+    return (size_t)W * (SD + 2) * 64 * (SD == 14 ? sizeof(short) : sizeof(int)) + (DYNAMIC == 2 ? (size_t)CRT_LDS_NODE_BYTES * NC : 0); // (14 levels: 16-bit entries)
+}
+template <bool COUNT_WORK, int SD, bool SS, int W, int NC, int DYNAMIC>
+__global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(CRT_WAVES_PER_EU, CRT_WAVES_PER_EU)))
+void render_kernel_dyn(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out, int *__restrict__ ids, unsigned long long *__restrict__ counters)
+{
+    render_body<COUNT_WORK, SD, SS, W, NC, DYNAMIC>(sc, cam, ra, out, ids, counters);
 }
 
 // =========================================================================================================
@@ -1192,7 +1202,9 @@ static bool launch_whole_tree(const SceneView &sc, const CameraPOD &cam, const R
 // workgroup no longer fits beside the large one (16 ms).
 #define CRT_NODE_CACHE_NODES_14 418 // 4 x 2 KB of stack (16-bit entries) + 418 x 56 B = 30.9 KB
 #define CRT_SPLIT_A_NODES_14 1328 // 16 x 2 KB   of stack + 1328 x 56 B = 104.6 KB (16-bit stack entries)
-#define CRT_SPLIT_B_NODES_14 CRT_NODE_CACHE_NODES_14 // 4 x 2 KB of stack + 418 x 56 B = 30.9 KB: the five-workgroup form's kernel
+#ifndef CRT_SPLIT_B_NODES_14
+#define CRT_SPLIT_B_NODES_14 800  //  4 x 2 KB   of stack +  800 x 56 B =  51.8 KB (all of it dynamic LDS)
+#endif
 #define CRT_SPLIT_A_NODES_16 1176 // 16 x 4.5 KB of stack + 1176 x 56 B = 136.3 KB
 #define CRT_SPLIT_B_NODES_16 76   //  4 x 4.5 KB of stack +   76 x 56 B =  22.2 KB
 #define CRT_SPLIT_A_NODES_24 508  // 16 x 6.5 KB of stack +  508 x 56 B = 131.8 KB
@@ -1205,25 +1217,29 @@ static bool launch_split(const SceneView &sc, const CameraPOD &cam, const Render
         if (!split || !split->helper) return false;
         constexpr int NA = SD == 14 ? CRT_SPLIT_A_NODES_14 : SD == 16 ? CRT_SPLIT_A_NODES_16 : CRT_SPLIT_A_NODES_24;
         constexpr int NB = SD == 14 ? CRT_SPLIT_B_NODES_14 : SD == 16 ? CRT_SPLIT_B_NODES_16 : CRT_SPLIT_B_NODES_24;
+        constexpr int NBC = SD == 14 ? CRT_NODE_CACHE_NODES_14 : NB; // (the instrumented small workgroup: static LDS below 32 KB)
         const uint32_t cus = (blocks + 19u) / 20u; // blocks = persistent waves, 20 per CU
         // the small workgroups start behind whatever the caller's stream holds, the caller's stream goes on behind them
         if (hipEventRecord(split->fork, stream) != hipSuccess || hipStreamWaitEvent(split->helper, split->fork, 0) != hipSuccess) return false;
         if constexpr (CW) {
-            // (the instrumented variant needs more registers than 96: it keeps the form with all of its LDS declared, 104-128 registers)
+            // (the instrumented variant needs more registers than 96: it keeps the forms with all of their LDS declared)
             hipLaunchKernelGGL((render_kernel<CW, SD, SS, 16, NA>), dim3(cus), dim3(1024), 0, stream, sc, cam, a, out, ids, counters);
+            hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, NBC>), dim3(cus), dim3(256), 0, split->helper, sc, cam, a, out, ids, counters);
         } else {
-            // (64-104 KB of dynamic LDS: allowed explicitly, once per device the kernel is launched on)
+            // (up to 104 KB of dynamic LDS: allowed explicitly, once per device the kernels are launched on)
             static std::atomic<uint64_t> allowed{ 0 };
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess) return false;
             if (dev < 64 && !(allowed.load(std::memory_order_relaxed) >> dev & 1u)) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel_large<CW, SD, SS, NA>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)large_stack_bytes<SD>()) != hipSuccess) { (void)hipGetLastError(); return false; }
+                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel_dyn<CW, SD, SS, 16, NA, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)dynamic_lds_bytes<SD, 16, NA, 1>()) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel_dyn<CW, SD, SS, 4, NB, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)dynamic_lds_bytes<SD, 4, NB, 2>()) != hipSuccess) { (void)hipGetLastError(); return false; }
                 allowed.fetch_or(1ull << dev, std::memory_order_relaxed);
             }
-            hipLaunchKernelGGL((render_kernel_large<CW, SD, SS, NA>), dim3(cus), dim3(1024), large_stack_bytes<SD>(), stream, sc, cam, a, out, ids, counters);
+            hipLaunchKernelGGL((render_kernel_dyn<CW, SD, SS, 16, NA, 1>), dim3(cus), dim3(1024), (dynamic_lds_bytes<SD, 16, NA, 1>()), stream, sc, cam, a, out, ids, counters);
+            hipLaunchKernelGGL((render_kernel_dyn<CW, SD, SS, 4, NB, 2>), dim3(cus), dim3(256), (dynamic_lds_bytes<SD, 4, NB, 2>()), split->helper, sc, cam, a, out, ids, counters);
         }
-        hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, NB>), dim3(cus), dim3(256), 0, split->helper, sc, cam, a, out, ids, counters);
         if (hipEventRecord(split->join, split->helper) != hipSuccess || hipStreamWaitEvent(stream, split->join, 0) != hipSuccess) return false;
         return true;
     }
