@@ -318,7 +318,8 @@ static_assert(CRT_WORK_STRIPES == 64u, "the order in which a wave visits the blo
 #define CRT_OCCUPANCY_ATTR
 #endif
 extern __shared__ int lds_dynamic[]; // render_kernel_dyn's stacks (DYNAMIC = 1) or node copy + stacks (DYNAMIC = 2), see there
-template <bool COUNT_WORK, int SD, bool SS, int W, int NC, int DYNAMIC = 0>
+// WHOLE: the launcher has checked that the whole node array is in the LDS copy (sc.nnodes <= NC): no device-memory node step exists
+template <bool COUNT_WORK, int SD, bool SS, int W, int NC, int DYNAMIC = 0, bool WHOLE = false>
 __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *__restrict__ out,
                                             int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
@@ -589,22 +590,23 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
                 // lanes are at cached nodes the step is LDS-only instead and the others wait.
                 bool in_lds = false;
                 int n_lds = 0;
-                if constexpr (NC > 0) {
+                if constexpr (WHOLE) { in_lds = inner; n_lds = n_inner; }
+                else if constexpr (NC > 0) {
                     in_lds = (unsigned)tv.cur < (unsigned)node_src.ncached; // leaf references and the end-of-walk value are beyond it as unsigned
                     n_lds = popc64(__ballot(in_lds));
                 }
-                if (NC > 0 && n_lds * CRT_LDS_VOTE_DEN >= n_inner * CRT_LDS_VOTE_NUM && n_lds >= n_leaf) {
+                if (NC > 0 && (WHOLE || n_lds * CRT_LDS_VOTE_DEN >= n_inner * CRT_LDS_VOTE_NUM) && n_lds >= n_leaf) {
                     if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_lds; } }
                     const SignOffsets so = sign_offsets(tv);
                     if (in_lds) trav_inner_lds_sorted(node_src.lds, so, tv, stack, cnt);
 #pragma unroll
                     for (int k = 1; k < CRT_LDS_STEPS_PER_VOTE; k++) {
-                        const bool again = in_lds && (unsigned)tv.cur < (unsigned)node_src.ncached;
+                        const bool again = in_lds && (WHOLE ? is_inner<NONE>(tv.cur) : (unsigned)tv.cur < (unsigned)node_src.ncached);
                         if constexpr (COUNT_WORK) { const int na = popc64(__ballot(again)); if (lane == 0) { wc[4]++; wc[5] += na; } }
                         if (again) trav_inner_lds_sorted(node_src.lds, so, tv, stack, cnt);
                     }
                     CRT_LAP(clk, 7);
-                } else if (n_inner >= n_leaf) {
+                } else if (!WHOLE && n_inner >= n_leaf) {
                     // (all lanes at a node take part: the loads cost the address unit the same whatever the number of lanes)
                     const bool mine = inner;
                     if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_inner; } }
@@ -678,11 +680,11 @@ template <int SD, int W, int NC, int DYNAMIC> constexpr size_t dynamic_lds_bytes
 {
     return (size_t)W * (SD + 2) * 64 * (SD == 14 ? sizeof(short) : sizeof(int)) + (DYNAMIC == 2 ? (size_t)CRT_LDS_NODE_BYTES * NC : 0); // (14 levels: 16-bit entries)
 }
-template <bool COUNT_WORK, int SD, bool SS, int W, int NC, int DYNAMIC>
+template <bool COUNT_WORK, int SD, bool SS, int W, int NC, int DYNAMIC, bool WHOLE = false>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(CRT_WAVES_PER_EU, CRT_WAVES_PER_EU)))
 void render_kernel_dyn(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out, int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
-    render_body<COUNT_WORK, SD, SS, W, NC, DYNAMIC>(sc, cam, ra, out, ids, counters);
+    render_body<COUNT_WORK, SD, SS, W, NC, DYNAMIC, WHOLE>(sc, cam, ra, out, ids, counters);
 }
 
 // =========================================================================================================
@@ -1237,7 +1239,19 @@ static bool launch_split(const SceneView &sc, const CameraPOD &cam, const Render
                                         (int)dynamic_lds_bytes<SD, 4, NB, 2>()) != hipSuccess) { (void)hipGetLastError(); return false; }
                 allowed.fetch_or(1ull << dev, std::memory_order_relaxed);
             }
-            hipLaunchKernelGGL((render_kernel_dyn<CW, SD, SS, 16, NA, 1>), dim3(cus), dim3(1024), (dynamic_lds_bytes<SD, 16, NA, 1>()), stream, sc, cam, a, out, ids, counters);
+            // (a tree that fits the large copy as a whole gets the kernel without device-memory node steps)
+            if (SD != 24 && sc.nnodes <= (uint32_t)NA) {
+                if constexpr (SD != 24) {
+                    static std::atomic<uint64_t> allowed_whole{ 0 };
+                    if (dev < 64 && !(allowed_whole.load(std::memory_order_relaxed) >> dev & 1u)) {
+                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel_dyn<CW, SD, SS, 16, NA, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)dynamic_lds_bytes<SD, 16, NA, 1>()) != hipSuccess) { (void)hipGetLastError(); return false; }
+                        allowed_whole.fetch_or(1ull << dev, std::memory_order_relaxed);
+                    }
+                    hipLaunchKernelGGL((render_kernel_dyn<CW, SD, SS, 16, NA, 1, true>), dim3(cus), dim3(1024), (dynamic_lds_bytes<SD, 16, NA, 1>()), stream, sc, cam, a, out, ids, counters);
+                }
+            } else
+                hipLaunchKernelGGL((render_kernel_dyn<CW, SD, SS, 16, NA, 1>), dim3(cus), dim3(1024), (dynamic_lds_bytes<SD, 16, NA, 1>()), stream, sc, cam, a, out, ids, counters);
             hipLaunchKernelGGL((render_kernel_dyn<CW, SD, SS, 4, NB, 2>), dim3(cus), dim3(256), (dynamic_lds_bytes<SD, 4, NB, 2>()), split->helper, sc, cam, a, out, ids, counters);
         }
         if (hipEventRecord(split->join, split->helper) != hipSuccess || hipStreamWaitEvent(stream, split->join, 0) != hipSuccess) return false;
