@@ -13,6 +13,7 @@ host cores on a bounded sample of the same workload (N = 1 only).
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -67,7 +68,9 @@ def pmc_traffic(workload, world):
         return None
     root = os.path.join(REPO, "profiles")
     best = None
-    for name in sorted(os.listdir(root)) if os.path.isdir(root) else []:
+    def natural(name):  # r2_v10_... after r2_v9_...
+        return [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", name)]
+    for name in sorted(os.listdir(root), key=natural) if os.path.isdir(root) else []:
         f = os.path.join(root, name, "pmc_render_kernel.json")
         b = os.path.join(root, name, "bench.json")
         if not (os.path.isfile(f) and os.path.isfile(b)):

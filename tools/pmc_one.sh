@@ -8,6 +8,6 @@ python3 - <<PY
 import csv, collections
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open('$OUT/p/p_counter_collection.csv')):
-    if 'kernel<false' in r['Kernel_Name'] or 'kernel_large<false' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+    if '<false' in r['Kernel_Name'] and 'render_kernel' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in agg.items(): print('$TAG %-32s %.4g' % (k, sum(v)/len(v)))
 PY

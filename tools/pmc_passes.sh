@@ -11,6 +11,6 @@ import csv, collections
 for n in ['p1','p2','p3']:
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open('$OUT/%s/%s_counter_collection.csv' % (n, n))):
-        if 'kernel<false' in r['Kernel_Name'] or 'kernel_large<false' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+        if '<false' in r['Kernel_Name'] and 'render_kernel' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in agg.items(): print('%-28s %.4g' % (k, sum(v)/len(v)))
 PY

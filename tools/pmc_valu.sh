@@ -9,7 +9,7 @@ import csv, collections, json
 rows = list(csv.DictReader(open('gpurun_out/pv_$T/pv_counter_collection.csv')))
 agg = collections.defaultdict(list)
 for r in rows:
-    if 'kernel<false' in r['Kernel_Name'] or 'kernel_large<false' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+    if '<false' in r['Kernel_Name'] and 'render_kernel' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
 line = [l for l in open('gpurun_out/pv_$T.log') if l.startswith('{')][-1]
 d = json.loads(line)
 d.update({k: sum(v)/len(v) for k, v in agg.items()}); d['T'] = $T

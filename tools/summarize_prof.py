@@ -15,6 +15,9 @@ import shutil
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+import re
+RENDER = re.compile(r"render_kernel\w*<false")                                   # the timed (not instrumented) render kernels
+LARGE = re.compile(r"render_kernel\w*<false, \d+, (true|false), 16,")          # ... with 16 waves per workgroup
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
 out = {}
@@ -23,7 +26,7 @@ for f in ["pmc_sq1", "pmc_sq2", "pmc_tcc1", "pmc_tcc2"]:
     # dispatches of the render kernels in start order; with two kernels per frame, consecutive pairs are frames
     disp_rows = collections.OrderedDict()
     for r in rows:
-        if "kernel<false" in r["Kernel_Name"] or "kernel_large<false" in r["Kernel_Name"]:
+        if RENDER.search(r["Kernel_Name"]):
             d = disp_rows.setdefault(r["Dispatch_Id"], {"name": r["Kernel_Name"], "start": int(r["Start_Timestamp"]), "end": int(r["End_Timestamp"]), "c": {}})
             d["c"][r["Counter_Name"]] = d["c"].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
             out.setdefault("kernels", {})[r["Kernel_Name"].split("(")[0]] = {"LDS_Block_Size": r["LDS_Block_Size"], "Scratch_Size": r["Scratch_Size"],
@@ -35,7 +38,7 @@ for f in ["pmc_sq1", "pmc_sq2", "pmc_tcc1", "pmc_tcc2"]:
     kinds = collections.defaultdict(list)
     for fr in frames_p:
         worker = max(fr, key=lambda d: d["end"] - d["start"])
-        kinds["large_kernel_first" if "large" in worker["name"] or per_frame == 1 else "small_kernel_first"].append(fr)
+        kinds["large_kernel_first" if LARGE.search(worker["name"]) or per_frame == 1 else "small_kernel_first"].append(fr)
     main = kinds["large_kernel_first"] or kinds["small_kernel_first"]
     def mean(frs, key):
         return sum(sum(d["c"].get(key, 0.0) for d in fr) for fr in frs) / len(frs)
@@ -51,7 +54,7 @@ for f in ["pmc_sq1", "pmc_sq2", "pmc_tcc1", "pmc_tcc2"]:
         out["pmc_pass_ns_per_frame"] = sum(sum(d["end"] - d["start"] for d in fr) for fr in main) / len(main)
 # the frame's duration where its kernels run together: the kernel trace, first start to last end of each frame
 disp = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in
-               csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_trace.csv"))) if "kernel<false" in r["Kernel_Name"] or "kernel_large<false" in r["Kernel_Name"]))
+               csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_trace.csv"))) if RENDER.search(r["Kernel_Name"])))
 frames_t = []
 for s0, e0, name in disp:
     if frames_t and s0 < frames_t[-1][1] and name not in frames_t[-1][2]:

@@ -3,6 +3,7 @@ the render kernel's dispatches of the timed region, how consecutive dispatches o
 the per-step kernel figure that must agree with the bench line's ms_per_step.
   python tools/trace_overlap.py <kernel_trace.csv> [bench.json] > profiles/<dir>/two_in_flight_trace.json"""
 import csv
+import re
 import json
 import sys
 
@@ -20,7 +21,7 @@ def col(r, *names):
 disp = []
 for r in rows:
     name = col(r, "Kernel_Name", "Name")
-    if "render_kernel<false" in name or "render_kernel_large<false" in name:
+    if re.search(r"render_kernel\w*<false", name):
         disp.append((int(col(r, "Start_Timestamp", "BeginNs")), int(col(r, "End_Timestamp", "EndNs")), col(r, "Queue_Id") if "Queue_Id" in r else "?"))
 disp.sort()
 # A frame that fills the GPU runs as two kernels at once (the 16 + 4 split: a 1024-thread and a 256-thread variant): the k-th
@@ -28,7 +29,7 @@ disp.sort()
 kinds = {}
 for r in rows:
     name = col(r, "Kernel_Name", "Name")
-    if "render_kernel<false" in name or "render_kernel_large<false" in name:
+    if re.search(r"render_kernel\w*<false", name):
         kinds.setdefault(name, []).append((int(col(r, "Start_Timestamp", "BeginNs")), int(col(r, "End_Timestamp", "EndNs")), col(r, "Queue_Id") if "Queue_Id" in r else "?"))
 kernels_per_frame = 1
 if len(kinds) == 2 and len(set(len(v) for v in kinds.values())) == 1:
