@@ -849,7 +849,7 @@ static int acquire_scratch(DeviceScene &d, hipStream_t stream, uint32_t chunks, 
         HIP_TRY(hipEventCreate(&x->ev0));
         HIP_TRY(hipEventCreate(&x->ev1));
         HIP_TRY(hipEventCreate(&x->ev_done));
-        HIP_TRY(make_split_streams(x->split, std::getenv("CRT_SPLIT_OWN_HELPER") ? nullptr : d.noalloc_split.helper));
+        HIP_TRY(make_split_streams(x->split, d.noalloc_split.helper)); // (the device's one helper stream, made at commit; own events)
     }
     if (chunks > 1) {
         const size_t need = chunk_slab_floats(rgb_floats, chunks);

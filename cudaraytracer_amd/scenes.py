@@ -105,6 +105,23 @@ def cat_grid(instances=1366, side=37, pitch=3.5, path=None):
     return d
 
 
+def terrain(n=50):
+    """A regular height field of 2 n^2 triangles over [-4, 4]^2 (Lambertian) + the reference spheres: SAH gives it a balanced,
+    shallow tree (n = 50: 5000 triangles, depth 12; n = 64: 8192 triangles, depth 14) -- a tree of at most 14 levels whose
+    leaf references do NOT fit 16 bits, the case the 16-bit-stack kernels must leave to the 32-bit ones."""
+    d = _base()
+    xs = np.linspace(-4.0, 4.0, n + 1, dtype=np.float32)
+    X, Z = np.meshgrid(xs, xs, indexing="ij")
+    Y = (0.4 * np.sin(1.7 * X) * np.cos(1.3 * Z) + 0.5).astype(np.float32)
+    verts = np.stack([X, Y, Z], -1).reshape(-1, 3).astype(np.float32)
+    a = (np.arange(n)[:, None] * (n + 1) + np.arange(n)[None, :]).reshape(-1).astype(np.uint32)
+    idx = np.concatenate([np.stack([a, a + 1, a + n + 1], -1), np.stack([a + 1, a + n + 2, a + n + 1], -1)], 0).astype(np.uint32)
+    d["materials"].append(dict(type=capi.MAT_LAMBERTIAN, rgb=(0.3, 0.6, 0.2), param=0.0, texture=None))
+    d["meshes"].append(dict(vertices=verts, indices=idx, material=0))
+    _add_ref_spheres(d)
+    return d
+
+
 # camera for config 4: the reference direction of view, pulled back along it to frame the 130-unit grid
 GRID_CAMERA = dict(lookfrom=(80.0, 50.0, -60.0), lookat=(-4.0, 0.0, 4.0))
 

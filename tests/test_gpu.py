@@ -199,6 +199,25 @@ def test_grid_scene_1m_triangles_sample(oracle, scenes, capi, node_cache):
     assert (ids >= 0).mean() > 0.5 and (ids < 999912).mean() > 0.2
 
 
+@pytest.mark.parametrize("n", [45, 50, 64])
+def test_shallow_trees_around_the_16_bit_reference_limit(oracle, scenes, capi, node_cache, n):
+    """The 14-level kernels keep 16-bit stack entries (crt_kernels.hip: LdsStack16), which only a tree with at most 4096
+    triangle slots and fewer than 32767 nodes may use.  Height fields of 4050 (fits), 5000 and 8192 triangles (do not fit;
+    depth 12 and 14, so only the reference width sends them to the 32-bit kernels), every kernel variant, bit-exact."""
+    desc = scenes.terrain(n)
+    s = scenes.build(desc, 0)
+    info = s.info()
+    assert info.num_triangles == 2 * n * n and info.bvh_depth <= 14
+    W, H, spp = 96, 54, 2
+    params, cam = scenes.make_camera(W)
+    rs = oracle.RefScene(desc)
+    fb, rids, _, rst = rs.render(oracle.make_camera(params, W), W, H, spp)
+    for chunks in (0, spp):
+        rgb, ids, st = s.render(cam, W, H, spp, want_ids=True, sample_chunks=chunks)
+        assert np.array_equal(ids, rids) and np.array_equal(rgb.reshape(fb.shape), fb) and st.rays == rst.rays, chunks
+    assert ((ids >= 0) & (ids < info.num_triangles)).mean() > 0.05   # the camera does see the mesh
+
+
 def test_frame_does_not_depend_on_the_schedule_knobs(monkeypatch, scenes, gpu_scenes):
     """A lane's own operation order is the sequential one whatever the wave does around it, so the knobs that only move
     work between lanes and waves -- units per trip to a block counter, the shade-phase threshold, waves per CU, interleaved
