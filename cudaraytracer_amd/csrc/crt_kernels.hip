@@ -1211,6 +1211,19 @@ static bool launch_whole_tree(const SceneView &sc, const CameraPOD &cam, const R
 #define CRT_SPLIT_B_NODES_16 76   //  4 x 4.5 KB of stack +   76 x 56 B =  22.2 KB
 #define CRT_SPLIT_A_NODES_24 508  // 16 x 6.5 KB of stack +  508 x 56 B = 131.8 KB
 #define CRT_SPLIT_B_NODES_24 16   //  4 x 6.5 KB of stack +   16 x 56 B =  26.9 KB
+// Up to 104 KB of dynamic LDS per workgroup: allowed explicitly, once per kernel and device.
+template <class Kernel>
+static bool allow_dynamic_lds(Kernel kernel, size_t bytes, std::atomic<uint64_t> &done, int dev)
+{
+    if (dev >= 64 || (done.load(std::memory_order_relaxed) >> dev & 1u)) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    done.fetch_or(1ull << dev, std::memory_order_relaxed);
+    return true;
+}
+
 template <bool CW, int SD, bool SS>
 static bool launch_split(const SceneView &sc, const CameraPOD &cam, const RenderArgs &a, float *out, int *ids, unsigned long long *counters, uint32_t blocks,
                          hipStream_t stream, const SplitStreams *split)
@@ -1228,31 +1241,17 @@ static bool launch_split(const SceneView &sc, const CameraPOD &cam, const Render
             hipLaunchKernelGGL((render_kernel<CW, SD, SS, 16, NA>), dim3(cus), dim3(1024), 0, stream, sc, cam, a, out, ids, counters);
             hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, NBC>), dim3(cus), dim3(256), 0, split->helper, sc, cam, a, out, ids, counters);
         } else {
-            // (up to 104 KB of dynamic LDS: allowed explicitly, once per device the kernels are launched on)
-            static std::atomic<uint64_t> allowed{ 0 };
             int dev = 0;
             if (hipGetDevice(&dev) != hipSuccess) return false;
-            if (dev < 64 && !(allowed.load(std::memory_order_relaxed) >> dev & 1u)) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel_dyn<CW, SD, SS, 16, NA, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)dynamic_lds_bytes<SD, 16, NA, 1>()) != hipSuccess ||
-                    hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel_dyn<CW, SD, SS, 4, NB, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)dynamic_lds_bytes<SD, 4, NB, 2>()) != hipSuccess) { (void)hipGetLastError(); return false; }
-                allowed.fetch_or(1ull << dev, std::memory_order_relaxed);
-            }
-            // (a tree that fits the large copy as a whole gets the kernel without device-memory node steps)
-            if (SD != 24 && sc.nnodes <= (uint32_t)NA) {
-                if constexpr (SD != 24) {
-                    static std::atomic<uint64_t> allowed_whole{ 0 };
-                    if (dev < 64 && !(allowed_whole.load(std::memory_order_relaxed) >> dev & 1u)) {
-                        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&render_kernel_dyn<CW, SD, SS, 16, NA, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)dynamic_lds_bytes<SD, 16, NA, 1>()) != hipSuccess) { (void)hipGetLastError(); return false; }
-                        allowed_whole.fetch_or(1ull << dev, std::memory_order_relaxed);
-                    }
-                    hipLaunchKernelGGL((render_kernel_dyn<CW, SD, SS, 16, NA, 1, true>), dim3(cus), dim3(1024), (dynamic_lds_bytes<SD, 16, NA, 1>()), stream, sc, cam, a, out, ids, counters);
-                }
-            } else
-                hipLaunchKernelGGL((render_kernel_dyn<CW, SD, SS, 16, NA, 1>), dim3(cus), dim3(1024), (dynamic_lds_bytes<SD, 16, NA, 1>()), stream, sc, cam, a, out, ids, counters);
-            hipLaunchKernelGGL((render_kernel_dyn<CW, SD, SS, 4, NB, 2>), dim3(cus), dim3(256), (dynamic_lds_bytes<SD, 4, NB, 2>()), split->helper, sc, cam, a, out, ids, counters);
+            // (a tree that fits the large copy as a whole gets the kernel without device-memory node steps; 24-level trees never do)
+            const bool whole = SD != 24 && sc.nnodes <= (uint32_t)NA;
+            const auto large = whole ? &render_kernel_dyn<CW, SD, SS, 16, NA, 1, SD != 24> : &render_kernel_dyn<CW, SD, SS, 16, NA, 1, false>;
+            const auto small = &render_kernel_dyn<CW, SD, SS, 4, NB, 2, false>;
+            static std::atomic<uint64_t> allowed[3]; // per kernel: the devices it has been allowed its dynamic LDS on
+            if (!allow_dynamic_lds(large, dynamic_lds_bytes<SD, 16, NA, 1>(), allowed[whole ? 1 : 0], dev) ||
+                !allow_dynamic_lds(small, dynamic_lds_bytes<SD, 4, NB, 2>(), allowed[2], dev)) return false;
+            hipLaunchKernelGGL(large, dim3(cus), dim3(1024), (dynamic_lds_bytes<SD, 16, NA, 1>()), stream, sc, cam, a, out, ids, counters);
+            hipLaunchKernelGGL(small, dim3(cus), dim3(256), (dynamic_lds_bytes<SD, 4, NB, 2>()), split->helper, sc, cam, a, out, ids, counters);
         }
         if (hipEventRecord(split->join, split->helper) != hipSuccess || hipStreamWaitEvent(stream, split->join, 0) != hipSuccess) return false;
         return true;
