@@ -3,14 +3,15 @@
 // render_kernel: persistent wave64 waves.  A lane owns one work unit at a time -- a pixel, or one chunk of a pixel's
 // samples -- taken in blocks of 2^fetch_shift units (RenderArgs, chosen by launch_render) from 64 striped block counters (units are numbered in 8x8-tile
 // order: the reference's block shape, kernel.cu:50-51, renderer.h:51-52); a unit's samples are summed in the lane in
-// sample order (renderer.h:28-32), so the float sum is the reference's whatever the partition.  Waves run four to a
-// workgroup and share an LDS copy of the top of the tree (CRT_NODE_CACHE_NODES = 236 nodes for trees up to 16 deep: 4 x
-// 4.6 KB of stack + 12 KB of nodes = 30 KB, five workgroups = 20 waves per CU; 64 nodes for trees up to 24 deep), or one
-// to a workgroup without it.  The traversal stack is an LDS column per lane (stack[level][lane]: bank = lane, conflict
-// free).
+// sample order (renderer.h:28-32), so the float sum is the reference's whatever the partition.  20 waves per CU in one of
+// three forms, chosen per frame by launch_render: one wave per workgroup (launches that do not fill the GPU); five 4-wave
+// workgroups that each share an LDS copy of the top of the tree (418 / 236 / 88 nodes beside stacks of 14 / 16 / 24
+// levels); or, for frames that fill the GPU many times over, TWO launches on one work queue -- one 16-wave workgroup per CU
+// whose LDS copy holds the whole node array of a small tree, and one 4-wave workgroup with what LDS is left (launch_split).
+// The traversal stack is an LDS column per lane (stack[level][lane]: bank = lane, conflict free), with 16-bit entries where
+// the tree's references fit a short.
 #include <hip/hip_runtime.h>
 #include <atomic>
-
 #include <mutex>
 
 #include "crt_kernels.h"
