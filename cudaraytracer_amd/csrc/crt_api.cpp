@@ -649,6 +649,7 @@ static int upload_replica(crt_scene *s, DeviceScene &d, int device)
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     d.cus = (uint32_t)prop.multiProcessorCount;
     HIP_TRY(noalloc_scratch_init(device)); // the device's copy of the static scratch of crt_render_noalloc (crt_kernels.hip)
+    (void)prepare_split_kernels();         // (a refusal only costs the two-launch form: launch_split then falls back)
     if (!d.noalloc_split.helper) {         // ... and the second stream of its two-launch frames (crt_kernels.hip: launch_split)
         HIP_TRY(make_split_streams(d.noalloc_split, nullptr));
     }

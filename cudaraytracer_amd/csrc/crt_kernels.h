@@ -59,6 +59,8 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
                          bool count_work, uint32_t max_waves, hipStream_t stream, const SplitStreams *split = nullptr);
 hipError_t launch_untile(const float *compact_all, uint32_t width, uint32_t height, uint32_t tile_ranks, float *out, hipStream_t stream);
 hipError_t launch_finalize_chunks(const float *slabs, uint32_t chunks, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream); // slabs [64-pixel block][chunk][64][3], n = 3 x pixels
+// The dynamic-LDS allowance of the two-launch frame's kernels on the current device (crt_kernels.hip: launch_split): called at commit.
+hipError_t prepare_split_kernels();
 hipError_t launch_sum_frames(const float *frames, uint32_t count, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream);      // frames n floats apart
 hipError_t launch_quantize(const float *rgb, size_t n, uint8_t *out, hipStream_t stream);
 hipError_t launch_finalize(const float *accum, size_t n, uint32_t total_spp, float *out, hipStream_t stream);

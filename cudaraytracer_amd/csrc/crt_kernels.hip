@@ -1225,6 +1225,25 @@ static bool allow_dynamic_lds(Kernel kernel, size_t bytes, std::atomic<uint64_t>
     return true;
 }
 
+// The kernels of a two-launch frame for a stack of SD levels and what LDS they ask for at launch (see launch_split).
+template <bool CW, int SD, bool SS>
+struct SplitKernels {
+    static constexpr int NA = SD == 14 ? CRT_SPLIT_A_NODES_14 : SD == 16 ? CRT_SPLIT_A_NODES_16 : CRT_SPLIT_A_NODES_24;
+    static constexpr int NB = SD == 14 ? CRT_SPLIT_B_NODES_14 : SD == 16 ? CRT_SPLIT_B_NODES_16 : CRT_SPLIT_B_NODES_24;
+    static constexpr size_t large_lds = dynamic_lds_bytes<SD, 16, NA, 1>(), small_lds = dynamic_lds_bytes<SD, 4, NB, 2>();
+    // (a tree that fits the large copy as a whole gets the kernel without device-memory node steps; 24-level trees never do)
+    static auto large(bool whole) { return whole ? &render_kernel_dyn<CW, SD, SS, 16, NA, 1, SD != 24> : &render_kernel_dyn<CW, SD, SS, 16, NA, 1, false>; }
+    static auto small() { return &render_kernel_dyn<CW, SD, SS, 4, NB, 2, false>; }
+    // allowed their dynamic LDS on `dev`: at commit (prepare_split_kernels), so that no frame -- crt_render_noalloc's included --
+    // has anything left to set up; launch_split asks again, which costs one load of a bit mask
+    static bool allow(int dev)
+    {
+        static std::atomic<uint64_t> done[3];
+        return allow_dynamic_lds(large(false), large_lds, done[0], dev) && allow_dynamic_lds(large(true), large_lds, done[1], dev) &&
+               allow_dynamic_lds(small(), small_lds, done[2], dev);
+    }
+};
+
 template <bool CW, int SD, bool SS>
 static bool launch_split(const SceneView &sc, const CameraPOD &cam, const RenderArgs &a, float *out, int *ids, unsigned long long *counters, uint32_t blocks,
                          hipStream_t stream, const SplitStreams *split)
@@ -1235,6 +1254,10 @@ static bool launch_split(const SceneView &sc, const CameraPOD &cam, const Render
         constexpr int NB = SD == 14 ? CRT_SPLIT_B_NODES_14 : SD == 16 ? CRT_SPLIT_B_NODES_16 : CRT_SPLIT_B_NODES_24;
         constexpr int NBC = SD == 14 ? CRT_NODE_CACHE_NODES_14 : NB; // (the instrumented small workgroup: static LDS below 32 KB)
         const uint32_t cus = (blocks + 19u) / 20u; // blocks = persistent waves, 20 per CU
+        if constexpr (!CW) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || !SplitKernels<CW, SD, SS>::allow(dev)) return false;
+        }
         // the small workgroups start behind whatever the caller's stream holds, the caller's stream goes on behind them
         if (hipEventRecord(split->fork, stream) != hipSuccess || hipStreamWaitEvent(split->helper, split->fork, 0) != hipSuccess) return false;
         if constexpr (CW) {
@@ -1242,17 +1265,9 @@ static bool launch_split(const SceneView &sc, const CameraPOD &cam, const Render
             hipLaunchKernelGGL((render_kernel<CW, SD, SS, 16, NA>), dim3(cus), dim3(1024), 0, stream, sc, cam, a, out, ids, counters);
             hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, NBC>), dim3(cus), dim3(256), 0, split->helper, sc, cam, a, out, ids, counters);
         } else {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess) return false;
-            // (a tree that fits the large copy as a whole gets the kernel without device-memory node steps; 24-level trees never do)
-            const bool whole = SD != 24 && sc.nnodes <= (uint32_t)NA;
-            const auto large = whole ? &render_kernel_dyn<CW, SD, SS, 16, NA, 1, SD != 24> : &render_kernel_dyn<CW, SD, SS, 16, NA, 1, false>;
-            const auto small = &render_kernel_dyn<CW, SD, SS, 4, NB, 2, false>;
-            static std::atomic<uint64_t> allowed[3]; // per kernel: the devices it has been allowed its dynamic LDS on
-            if (!allow_dynamic_lds(large, dynamic_lds_bytes<SD, 16, NA, 1>(), allowed[whole ? 1 : 0], dev) ||
-                !allow_dynamic_lds(small, dynamic_lds_bytes<SD, 4, NB, 2>(), allowed[2], dev)) return false;
-            hipLaunchKernelGGL(large, dim3(cus), dim3(1024), (dynamic_lds_bytes<SD, 16, NA, 1>()), stream, sc, cam, a, out, ids, counters);
-            hipLaunchKernelGGL(small, dim3(cus), dim3(256), (dynamic_lds_bytes<SD, 4, NB, 2>()), split->helper, sc, cam, a, out, ids, counters);
+            typedef SplitKernels<CW, SD, SS> K;
+            hipLaunchKernelGGL(K::large(SD != 24 && sc.nnodes <= (uint32_t)NA), dim3(cus), dim3(1024), K::large_lds, stream, sc, cam, a, out, ids, counters);
+            hipLaunchKernelGGL(K::small(), dim3(cus), dim3(256), K::small_lds, split->helper, sc, cam, a, out, ids, counters);
         }
         if (hipEventRecord(split->join, split->helper) != hipSuccess || hipStreamWaitEvent(stream, split->join, 0) != hipSuccess) return false;
         return true;
@@ -1280,6 +1295,17 @@ static void launch_lanes(const SceneView &sc, const CameraPOD &cam, const Render
         }
     }
     hipLaunchKernelGGL((render_kernel<CW, SD, SS, 1, 0>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
+}
+
+// At commit, with the scene's device current: everything a two-launch frame would otherwise set up on its first use.
+hipError_t prepare_split_kernels()
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool ok = SplitKernels<false, 14, false>::allow(dev) && SplitKernels<false, 14, true>::allow(dev) && SplitKernels<false, 16, false>::allow(dev) &&
+                    SplitKernels<false, 16, true>::allow(dev) && SplitKernels<false, 24, false>::allow(dev) && SplitKernels<false, 24, true>::allow(dev);
+    return ok ? hipSuccess : hipErrorInvalidValue; // (not fatal for the caller: launch_split falls back to the one-launch form)
 }
 
 hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,

@@ -16,6 +16,7 @@ hipError_t lbvh_build(const float *, const int *, uint32_t, const Box &, bool, c
 hipError_t launch_quantize(const float *, size_t, uint8_t *, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_finalize_chunks(const float *, uint32_t, size_t, uint32_t, bool, float *, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_sum_frames(const float *, uint32_t, size_t, uint32_t, bool, float *, hipStream_t) { return hipErrorNoDevice; }
+hipError_t prepare_split_kernels() { return hipErrorNoDevice; }
 hipError_t noalloc_scratch_init(int) { return hipErrorNoDevice; }
 void *noalloc_scratch_ptr(int) { return nullptr; }
 } // namespace crt
