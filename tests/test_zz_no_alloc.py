@@ -45,6 +45,30 @@ def test_noalloc_matches_crt_render_twice_in_a_row(capi, scenes, monkeypatch, no
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize("node_cache, size", [("1", (480, 270, 4, 4)), ("4", (1536, 864, 8, 2))])
+def test_noalloc_under_stream_capture(capi, scenes, monkeypatch, node_cache, size):
+    """What the entry point is for: captured into a HIP graph (torch.cuda.graph) -- one launch, or the two-launch form with its
+    helper stream forked and joined by events -- the capture itself renders nothing, every replay renders crt_render's frame."""
+    import torch
+    monkeypatch.setenv("CRT_NODE_CACHE", node_cache)
+    W, H, spp, chunks = size
+    s = scenes.build(scenes.cats(), 0)
+    _, cam = scenes.make_camera(W)
+    want = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
+    s.render(cam, W, H, spp, out_rgb=want.data_ptr(), sample_chunks=chunks, flags=capi.OUT_DEVICE)
+    got = torch.zeros_like(want)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=torch.cuda.Stream()):
+        capi.render_noalloc(s, cam, W, H, spp, got.data_ptr(), sample_chunks=chunks, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert bool((got == 0).all().item())
+    for _ in range(2):
+        got.fill_(-1.0)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+
+
 def test_noalloc_rejects_what_does_not_fit(capi, scenes):
     import torch
     s = scenes.build(scenes.cat(), 0)
