@@ -42,6 +42,9 @@ public:
         cam.background[0] = (*d_camera)->background.x; // Camera::background is a public member (camera.h:23)
         cam.background[1] = (*d_camera)->background.y;
         cam.background[2] = (*d_camera)->background.z;
+        // ... and so is Camera::defocus_angle (camera.h:20), the value get_ray tests (camera.h:94): the constructor leaves the
+        // member at its default 0.6 (its parameter shadows it), a caller that writes 0 to it gets the pinhole branch
+        cam.defocus_angle = (*d_camera)->defocus_angle;
         if (devices.empty()) {
             checkCrtErrors(crt_render((*d_world)->scene, &cam, &p, &framebuffer[0].x, nullptr, &last_stats));
             return;

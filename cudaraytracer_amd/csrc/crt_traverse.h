@@ -20,6 +20,17 @@
 // candidate in the window, each time extracting the next rank, so it needs no storage.  It runs for a few
 // rays per million.  Box tests only prune: boxes contain the reference's own 1e-4-padded leaf boxes
 // (triangle.h:28-41) plus a margin that covers the rounding of the slab arithmetic below (crt_bvh.cpp).
+//
+// One case is EXCLUDED from this argument, because there the reference's box test is not "purely geometric":
+// a direction component of exactly +-0 together with an origin that lies, in that component and bit for bit, on
+// a plane of one of the reference's node boxes.  aabb.h:73-78 then forms 0 * inf = NaN, and glm's min / max
+// (first operand returned when either is NaN) turn it into a miss of that box -- always on a max plane, on a
+// min plane for the x axis only (tests/test_oracle.py::test_slab_test_nan_case_depends_on_the_axis records what
+// the restatement returns) -- although the ray runs inside the box's closed slab, so the reference skips a
+// subtree whose primitives this walk would test (here the reciprocal is clamped to +-1e30 and 0 * 1e30 = 0).
+// Generated rays do not reach it: a camera direction is pixel_center - origin (camera.h:96) and a scattered one
+// normal + random_unit_vector (material.h:25), whose components vanish only by exact cancellation, and the
+// origin -- a hit point o + t d -- would in addition have to equal a coordinate of a 1e-4-padded triangle box.
 #pragma once
 
 #include "crt_core.h"

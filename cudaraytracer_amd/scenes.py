@@ -34,6 +34,10 @@ def make_camera(width, **overrides):
     if p.get("background") is not None:  # Camera::background is a public member (camera.h:23), default (0,0,0)
         for k in range(3):
             cam.background[k] = float(p["background"][k])
+    # Camera::defocus_angle is a public member too (camera.h:20); the constructor's parameter of the same name shadows it, so
+    # it stays 0.6 unless the caller writes it afterwards -- and it is the member that get_ray tests (camera.h:94)
+    if p.get("member_defocus_angle") is not None:
+        cam.defocus_angle = float(p["member_defocus_angle"])
     return p, cam
 
 

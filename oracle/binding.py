@@ -131,6 +131,9 @@ def make_camera(params, width):
         import struct
         n = len(cam.buf.raw)
         cam.buf[n - 12:n] = struct.pack("<3f", *[float(x) for x in params["background"]])
+    if params.get("member_defocus_angle") is not None:  # camera.h:20, tested by get_ray (camera.h:94): ref_camera.defocus_angle, byte 8
+        import struct
+        cam.buf[8:12] = struct.pack("<f", float(params["member_defocus_angle"]))
     return cam
 
 

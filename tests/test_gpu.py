@@ -499,11 +499,15 @@ def test_degenerate_trees_from_the_gpu_builder(oracle, scenes, capi, kind):
     assert np.array_equal(ids, rids) and np.array_equal(rgb, fb) and st.rays == rst.rays
 
 
-@pytest.mark.parametrize("camera", [dict(defocus_angle=0.0), dict(defocus_angle=4.0, vfov=60.0, lookfrom=(-3.0, 2.0, 7.0), lookat=(0.0, 1.0, 0.0)),
+@pytest.mark.parametrize("camera", [dict(defocus_angle=0.0), dict(member_defocus_angle=0.0), dict(member_defocus_angle=-1.0, defocus_angle=4.0),
+                                    dict(defocus_angle=4.0, vfov=60.0, lookfrom=(-3.0, 2.0, 7.0), lookat=(0.0, 1.0, 0.0)),
                                     dict(vfov=10.0, aspect=1.0, lookfrom=(0.0, 9.0, 0.5), lookat=(0.0, 0.0, 0.0), vup=(0.0, 0.0, -1.0))])
 def test_other_cameras(oracle, scenes, gpu_scenes, node_cache, camera):
-    """Pinhole camera (no defocus disk: camera.h:89 takes the centre), a wide lens (most disk draws are retried at least once
-    somewhere in a wave), a top view with another up vector and a square aspect."""
+    """A constructor defocus_angle of 0 (the disk has radius 0 but is still sampled: the parameter shadows the member, which
+    stays 0.6, camera.h:20,55,94); the MEMBER Camera::defocus_angle written to 0 or below after construction, which is what
+    takes get_ray's pinhole branch (camera.h:94: the centre is the origin and no disk draw is made -- another shape of the
+    camera stage's random stream); a wide lens (most disk draws are retried at least once somewhere in a wave); a top view
+    with another up vector and a square aspect."""
     _compare(oracle, scenes, gpu_scenes, "cats", 120, 67 if "aspect" not in camera else 120, 3, camera=camera, ids_sample=2)
 
 

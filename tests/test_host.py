@@ -119,6 +119,34 @@ def test_single_stepped_product_code_is_bit_exact_with_oracle(hostsim, oracle, s
     assert hs["nodes"] * 2 < st.box_tests                     # and the product BVH does far less work per ray
 
 
+def test_member_defocus_angle_takes_the_pinhole_branch(hostsim, oracle, scenes):
+    """camera.h:94: get_ray tests the MEMBER defocus_angle.  The constructor leaves it at 0.6 whatever its parameter says
+    (F12); a caller that writes 0 (or less) to the public member afterwards gets rays from the camera centre and no disk
+    draws.  Product code (single-stepped) against the oracle, and the ray itself against first principles."""
+    desc = scenes.cat()
+    s = hostsim.build(desc)
+    rs = oracle.RefScene(desc)
+    W, H = 96, 54
+    for angle in (0.0, -2.0):
+        params, cam = scenes.make_camera(W, member_defocus_angle=angle)
+        assert cam.defocus_angle == angle
+        rc = oracle.make_camera(params, W)
+        o, d = rc.get_ray(W, 40, 20, 3, 1984)
+        assert np.array_equal(o, np.array(params["lookfrom"], np.float32))       # the centre itself, bit for bit
+        fb, ids, _, st = rs.render(rc, W, H, 3)
+        out, oid, hs = hostsim.render(s, cam, W, H, 3)
+        assert np.array_equal(ids, oid) and np.array_equal(fb, out) and st.rays == hs["rays"]
+    # the branch changes the frame: with the member at its default the disk is sampled
+    params, cam = scenes.make_camera(W)
+    out_disk, _, _ = hostsim.render(s, cam, W, H, 3)
+    assert not np.array_equal(out, out_disk)
+    # a constructor parameter of 0 does NOT take the branch: radius 0, but the draws are made (same origin, other code path)
+    params0, cam0 = scenes.make_camera(W, defocus_angle=0.0)
+    assert cam0.defocus_angle == np.float32(0.6)
+    o0, _ = oracle.make_camera(params0, W).get_ray(W, 40, 20, 3, 1984)
+    assert np.array_equal(o0, np.array(params0["lookfrom"], np.float32))
+
+
 def test_depth_parameter_and_sample_offset(hostsim, oracle, scenes):
     desc = scenes.cat()
     s = hostsim.build(desc)

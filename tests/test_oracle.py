@@ -117,6 +117,34 @@ def test_slab_test_ignores_interval_and_handles_zero_direction(oracle):
     assert not oracle.slab_test((0, 0, 0), (1, 1, 1), (-1, 0.0, 1.5), (1, 0, 0))
 
 
+def test_slab_test_nan_case_depends_on_the_axis(oracle):
+    """aabb.h:73-91 with a direction component of +-0 and the origin EXACTLY on one of that axis' box planes: (plane - o) *
+    (1 / 0) = 0 * inf = NaN for that plane.  glm::min(a, b) = (b < a) ? b : a and glm::max(a, b) = (a < b) ? b : a return
+    their FIRST operand when either is NaN, so in max(max(tNear.x, tNear.y), tNear.z) a NaN in y or z is dropped (second
+    operand) while a NaN in x is the first operand of both reductions and survives: tmin = NaN, `tmin <= tmax` is false, the
+    reference MISSES the box although the ray runs along its face; on the max plane the NaN turns tFar into -inf and every
+    axis misses.  This KAT records what the restatement does; the product's
+    pruning arithmetic (crt_traverse.h: reciprocal clamped to +-1e30, so 0 * 1e30 = 0) visits such a box, i.e. this one case is
+    outside the equivalence argument of DESIGN.md section 2 -- it needs a path segment whose direction has an exactly zero
+    component AND whose origin equals, in that component and bit for bit, a 1e-4-padded box plane of the reference tree."""
+    box = ((0, 0, 0), (1, 1, 1))
+    for zero in (0.0, -0.0):
+        # x axis: origin.x on the min plane (t0.x = NaN: first operand of glm::min -> tNear.x = NaN) or on the max plane
+        # (t1.x = NaN: glm::min(t0, NaN) = t0 = -inf/+inf side, glm::max(t0, NaN) = t0): only the first poisons tmin
+        assert not oracle.slab_test(*box, (0.0, -1.0, 0.5), (zero, 1.0, 0.0))      # NaN survives -> miss (the reference's quirk)
+        # y / z axes: the NaN is a second operand of the reductions and is dropped -> the other axes decide -> hit
+        assert oracle.slab_test(*box, (-1.0, 0.0, 0.5), (1.0, zero, 0.0))
+        assert oracle.slab_test(*box, (-1.0, 0.5, 0.0), (1.0, 0.0, zero))
+        # origin on the MAX plane of the zero axis: t1 = NaN, t0 = -inf, glm::max(-inf, NaN) = -inf -> tFar = -inf on that axis
+        # -> tmax = -inf: a miss whatever the axis
+        assert not oracle.slab_test(*box, (1.0, -1.0, 0.5), (zero, 1.0, 0.0))
+        assert not oracle.slab_test(*box, (-1.0, 1.0, 0.5), (1.0, zero, 0.0))
+        assert not oracle.slab_test(*box, (-1.0, 0.5, 1.0), (1.0, 0.0, zero))
+    # a zero component with the origin strictly inside / outside the slab: +-inf, no NaN, the ordinary answers
+    assert oracle.slab_test(*box, (0.5, -1.0, 0.5), (0.0, 1.0, 0.0))
+    assert not oracle.slab_test(*box, (1.5, -1.0, 0.5), (0.0, 1.0, 0.0))
+
+
 def test_triangle_hit_cases(oracle):
     a, b, c = (0, 0, 0), (1, 0, 0), (0, 1, 0)
     t, n, front = oracle.triangle_hit(a, b, c, (0.25, 0.25, 1), (0, 0, -1))
