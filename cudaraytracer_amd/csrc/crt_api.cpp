@@ -245,6 +245,10 @@ struct Tuning {
     int stripe_bands = 1;      // CRT_STRIPE_BANDS: each block counter owns a contiguous band of the frame
     int waves_per_cu = 20;     // CRT_WAVES_PER_CU: persistent waves launched per compute unit (96 VGPRs: 5 per SIMD)
     int print_sections = 0;    // CRT_PRINT_SECTIONS: with CRT_COUNT_WORK and stats, print the section clocks
+    int chunk_mode = 0;        // CRT_CHUNK_MODE: sample chunks through slabs + a second kernel (1), through the waves' rings (2), or chosen per frame (0)
+    int slab_budget_mb = 2048; // CRT_SLAB_BUDGET_MB: the largest chunk scratch a frame may ask for before it takes the ring instead
+    int ring_batch = 0;        // CRT_RING_BATCH: sample chunks, complete blocks a wave lets collect before one pass adds them up (0 = default)
+    int ring_slots = 0;        // CRT_RING_SLOTS: sample chunks, blocks a wave may have in flight in its ring (2..16; 0 = default, crt_kernels.h)
     void from_env()
     {
         kernel = get_env_int("CRT_KERNEL", 0) == 1 ? 1 : 0;
@@ -255,6 +259,10 @@ struct Tuning {
         stripe_bands = get_env_int("CRT_STRIPE_BANDS", 1) ? 1 : 0;
         waves_per_cu = std::min(std::max(get_env_int("CRT_WAVES_PER_CU", 20), 1), 64);
         print_sections = get_env_int("CRT_PRINT_SECTIONS", 0);
+        ring_slots = std::min(std::max(get_env_int("CRT_RING_SLOTS", 0), 0), 16);
+        ring_batch = std::min(std::max(get_env_int("CRT_RING_BATCH", 0), 0), 8);
+        chunk_mode = std::min(std::max(get_env_int("CRT_CHUNK_MODE", 0), 0), 2);
+        slab_budget_mb = std::max(get_env_int("CRT_SLAB_BUDGET_MB", 2048), 0);
     }
 };
 
@@ -262,12 +270,16 @@ struct Tuning {
 // order by finalize_chunks_kernel), the staging buffers of host-pointer renders (grow only) and the timing events.  Calls
 // on one stream are ordered and share a set; calls on different streams get different sets, so their kernels may overlap
 // (the next frame fills the GPU while this one's last waves drain) and two host-pointer renders never share staging.
+// How a frame with sample chunks is rendered: through slabs and a second kernel, or through the waves' rings (crt_kernels.h: CM_*).
+struct ChunkPlan { uint32_t mode = CM_WHOLE, ring_slots = 0; size_t bytes = 0; };
+
 struct StreamScratch {
     hipStream_t stream = nullptr; bool used = false, recorded = false; uint64_t last_use = 0;
     unsigned long long *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr; // around the render kernel; after the last use of the set
     SplitStreams split{ nullptr, nullptr, nullptr };           // second stream + fork / join events for the two-launch frame (crt_kernels.hip: launch_split)
-    float *d_chunk_slabs = nullptr; size_t chunk_slab_floats = 0;
+    float *d_chunks = nullptr; size_t chunk_bytes = 0; // sample chunks: the slabs [pixel][chunk][3] or the waves' rings (crt_kernels.h), whichever the frame uses
+    ChunkPlan plan;                                      // ... of the frame last enqueued with this set
     float *d_stage_rgb = nullptr; size_t stage_rgb_floats = 0;
     int *d_stage_ids = nullptr; size_t stage_ids = 0;
 };
@@ -315,7 +327,7 @@ struct DeviceScene {
         noalloc_split = SplitStreams{ nullptr, nullptr, nullptr }; // (the per-stream sets below only borrowed the helper stream)
         for (StreamScratch &x : scratch) {
             if (x.d_counters) (void)hipFree(x.d_counters);
-            if (x.d_chunk_slabs) (void)hipFree(x.d_chunk_slabs);
+            if (x.d_chunks) (void)hipFree(x.d_chunks);
             if (x.d_stage_rgb) (void)hipFree(x.d_stage_rgb);
             if (x.d_stage_ids) (void)hipFree(x.d_stage_ids);
             if (x.ev0) (void)hipEventDestroy(x.ev0);
@@ -782,15 +794,7 @@ static int check_render_params(const crt_scene *s, const crt_camera *cam, const 
     if (p->width > 65535u || p->height > 65535u || p->spp > 65535u || p->max_depth > 255u)
         return fail(CRT_ERR_LIMIT, w + ": width, height, spp must be <= 65535 and max_depth <= 255 (packed lane state)");
     const uint32_t chunks = p->sample_chunks > 1 ? p->sample_chunks : 1u;
-    if (chunks > 1 && ((chunks & (chunks - 1u)) != 0 || p->spp % chunks != 0 || chunks > 1024u))
-        return fail(CRT_ERR_INVALID, w + ": sample_chunks must be a power of two (<= 1024) that divides spp");
-    if (chunks > 1) {
-        const uint64_t tiles = (uint64_t)((p->width + 7u) / 8u) * ((p->height + 7u) / 8u);
-        const uint64_t units = ((tiles + p->tile_ranks - 1) / p->tile_ranks) * 64u * chunks;
-        if (units >= (1ull << 31)) return fail(CRT_ERR_LIMIT, w + ": pixels x sample_chunks does not fit the work counter");
-        // a partial row-major render (tile_ranks > 1 without CRT_OUT_COMPACT) leaves other ranks' pixels untouched
-        if (p->tile_ranks > 1 && !(p->flags & CRT_OUT_COMPACT)) return fail(CRT_ERR_INVALID, w + ": sample_chunks with tile_ranks > 1 needs CRT_OUT_COMPACT");
-    }
+    if (chunks > 1 && p->spp % chunks != 0) return fail(CRT_ERR_INVALID, w + ": sample_chunks must divide spp");
     *chunks_out = chunks;
     return CRT_OK;
 }
@@ -800,15 +804,10 @@ static size_t output_floats(const crt_render_params *p)
     return (p->flags & CRT_OUT_COMPACT) ? (size_t)crt_compact_floats(p->width, p->height, p->tile_ranks) : (size_t)p->width * p->height * 3;
 }
 
-// One frame's kernels on `stream` of the copy `d` (whose device is current): clears the counters and runs the render kernel
-// into d_rgb -- with sample chunks into the slabs, followed by the chunk-sum pass.  ev0 / ev1 (nullable) are recorded around
-// the render kernel.  Allocates nothing.
-static int enqueue_render(const crt_scene *s, const DeviceScene &d, const crt_camera *cam, const crt_render_params *p, uint32_t chunks, float *d_rgb,
-                          int *d_ids, unsigned long long *d_counters, float *d_slabs, hipEvent_t ev0, hipEvent_t ev1, hipStream_t stream,
-                          const SplitStreams *split)
+// The frame's kernel arguments as far as the caller decides them (launch_render completes the work queue's geometry).
+static RenderArgs render_args(const crt_scene *s, const crt_render_params *p, uint32_t chunks)
 {
     const Tuning &t = s->tuning;
-    const size_t rgb_floats = output_floats(p);
     RenderArgs ra{};
     ra.width = p->width; ra.height = p->height; ra.tiles_x = (p->width + 7u) / 8u; ra.tiles_y = (p->height + 7u) / 8u;
     ra.spp = p->spp; ra.sample_offset = p->sample_offset; ra.max_depth = p->max_depth; ra.ids_sample = p->ids_sample;
@@ -816,31 +815,69 @@ static int enqueue_render(const crt_scene *s, const DeviceScene &d, const crt_ca
     ra.flags = ((p->flags & CRT_OUT_ACCUM) ? (uint32_t)RA_ACCUM : 0u) | ((p->flags & CRT_OUT_COMPACT) ? (uint32_t)RA_COMPACT : 0u);
     ra.key0 = (uint32_t)p->seed; ra.key1 = (uint32_t)(p->seed >> 32);
     // the pool kernel has no sample chunks: chosen here with launch_render's own condition, and the threshold with it
-    const bool pool = t.kernel == 1 && chunks == 1;
+    const bool pool = t.kernel == 1 && chunks == 1 && pool_kernel_built();
     ra.kernel = pool ? (uint32_t)RK_POOL : (uint32_t)RK_LANES;
     ra.sched_threshold = (uint32_t)(pool ? t.pool_refill : t.sched_threshold);
     ra.bvh_depth = s->bvh.depth;
     ra.node_cache = (uint32_t)t.node_cache;
-    ra.fetch_shift = 0;
-    while (t.fetch_block > 1 && (2u << ra.fetch_shift) <= (uint32_t)t.fetch_block) ra.fetch_shift++; // floor(log2); 0 = launch_render's rule
+    ra.fetch_units = (uint32_t)t.fetch_block;         // 0 = launch_render's rule
     ra.blocks_per_stripe = t.stripe_bands ? 1u : 0u; // bands by default (+0.5 % cats, +2 % on the 1 M-triangle grid); launch_render sets the count
     ra.chunks = chunks;
+    ra.chunk_mode = chunks > 1 ? (uint32_t)CM_RING : (uint32_t)CM_WHOLE; // (plan_chunks decides between ring and slabs)
+    ra.ring_slots = (uint32_t)t.ring_slots;
+    ra.ring_batch = (uint32_t)t.ring_batch;
+    return ra;
+}
+
+// Sample chunks, two ways (same frame bit for bit).  Slabs: every chunk's raw sum goes to a scratch of pixels x chunks x 12 bytes and
+// a second kernel adds a pixel's chunk sums -- the fastest (7.9 ms on the headline frame against 8.4 through the rings: the waves
+// neither count nor add), but 1.6 GB for 1080p x 64 chunks and 25 GB for 1080p x 1024.  Rings: the wave that rendered a block of
+// pixels adds them up itself through a ring of a few KB per wave, a fixed 30 - 130 MB per stream whatever the frame, any chunk count.
+// Chosen per frame: slabs while they fit `budget` bytes (Tuning::slab_budget_mb; crt_render_noalloc: its static scratch) and the
+// frame is whole or compact (the second kernel writes every pixel of `out`), else the ring with as many slots as fit.
+static ChunkPlan plan_chunks(const crt_scene *s, const DeviceScene &d, const crt_render_params *p, uint32_t chunks, size_t budget, bool ring_must_fit)
+{
+    ChunkPlan plan;
+    if (chunks <= 1) return plan;
+    const Tuning &t = s->tuning;
+    const size_t slab_bytes = output_floats(p) * (size_t)chunks * sizeof(float);
+    const bool slab_ok = !(p->tile_ranks > 1 && !(p->flags & CRT_OUT_COMPACT)) && slab_bytes <= budget && (uint64_t)(output_floats(p) / 3) * chunks < (1ull << 32); // (32-bit unit index)
+    if (t.chunk_mode == 1 ? slab_ok : (t.chunk_mode == 0 && slab_ok)) { plan.mode = CM_SLAB; plan.bytes = slab_bytes; return plan; }
+    RenderArgs ra = render_args(s, p, chunks);
+    ra.chunk_mode = CM_RING;
+    const uint32_t waves = d.cus * (uint32_t)t.waves_per_cu;
+    plan.mode = CM_RING;
+    plan.ring_slots = ring_must_fit ? render_ring_slots_that_fit(ra, waves, budget) : (ra.ring_slots ? std::min(std::max(ra.ring_slots, 2u), 16u) : CRT_RING_SLOTS_DEFAULT);
+    plan.bytes = plan.ring_slots ? render_ring_bytes(ra, waves, plan.ring_slots) : 0;
+    return plan;
+}
+
+// One frame's kernels on `stream` of the copy `d` (whose device is current): clears the counters and runs the render kernel
+// into d_rgb; with sample chunks through d_chunks as `plan` says (slabs + the chunk-sum pass, or the waves' rings).  ev0 / ev1
+// (nullable) are recorded around the render kernel.  Allocates nothing.
+static int enqueue_render(const crt_scene *s, const DeviceScene &d, const crt_camera *cam, const crt_render_params *p, uint32_t chunks, float *d_rgb,
+                          int *d_ids, unsigned long long *d_counters, float *d_chunks, const ChunkPlan &plan, hipEvent_t ev0, hipEvent_t ev1, hipStream_t stream,
+                          const SplitStreams *split)
+{
+    const Tuning &t = s->tuning;
+    RenderArgs ra = render_args(s, p, chunks);
+    ra.chunk_mode = plan.mode;
     float *d_target = d_rgb;
-    if (chunks > 1) { d_target = d_slabs; ra.flags |= (uint32_t)RA_ACCUM; } // raw chunk sums, [pixel][chunk][3]
+    if (plan.mode == CM_RING) {
+        ra.ring_lo = (uint32_t)(uintptr_t)d_chunks; ra.ring_hi = (uint32_t)((uint64_t)(uintptr_t)d_chunks >> 32);
+        ra.ring_slots = plan.ring_slots;
+    } else if (plan.mode == CM_SLAB) d_target = d_chunks; // raw chunk sums, [pixel][chunk][3]
     HIP_TRY(hipMemsetAsync(d_counters, 0, CRT_COUNTER_BYTES, stream));
     if (ev0) HIP_TRY(hipEventRecord(ev0, stream));
     HIP_TRY(launch_render(d.view, *reinterpret_cast<const CameraPOD *>(cam), ra, d_target, d_ids, d_counters, (p->flags & CRT_COUNT_WORK) != 0,
                           d.cus * (uint32_t)t.waves_per_cu, stream, t.waves_per_cu == 20 ? split : nullptr)); // (the split is 16 + 4 waves per CU)
     if (ev1) HIP_TRY(hipEventRecord(ev1, stream));
-    if (chunks > 1) HIP_TRY(launch_finalize_chunks(d_slabs, chunks, rgb_floats, p->spp, (p->flags & CRT_OUT_ACCUM) != 0, d_rgb, stream));
+    if (plan.mode == CM_SLAB) HIP_TRY(launch_finalize_chunks(d_chunks, chunks, output_floats(p), p->spp, (p->flags & CRT_OUT_ACCUM) != 0, d_rgb, stream));
     return CRT_OK;
 }
 
-// floats of chunk scratch a frame needs: blocks of 64 pixels x chunks x 64 x 3 (crt_kernels.hip: finalize_chunks_kernel)
-static size_t chunk_slab_floats(size_t rgb_floats, uint32_t chunks) { return (rgb_floats / 3 + 63) / 64 * 192 * chunks; }
-
 // The scratch set of `stream` on `d`, with counters, events and (sample chunks) slabs of the size this frame needs.
-static int acquire_scratch(DeviceScene &d, hipStream_t stream, uint32_t chunks, size_t rgb_floats, StreamScratch **out)
+static int acquire_scratch(const crt_scene *s, DeviceScene &d, hipStream_t stream, const crt_render_params *p, uint32_t chunks, StreamScratch **out)
 {
     hipEvent_t handover = nullptr;
     StreamScratch *x = d.scratch_for(stream, &handover);
@@ -852,14 +889,12 @@ static int acquire_scratch(DeviceScene &d, hipStream_t stream, uint32_t chunks, 
         HIP_TRY(hipEventCreate(&x->ev_done));
         HIP_TRY(make_split_streams(x->split, d.noalloc_split.helper)); // (the device's one helper stream, made at commit; own events)
     }
-    if (chunks > 1) {
-        const size_t need = chunk_slab_floats(rgb_floats, chunks);
-        if (x->chunk_slab_floats < need) {
-            if (x->d_chunk_slabs) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(x->d_chunk_slabs); }
-            x->d_chunk_slabs = nullptr; x->chunk_slab_floats = 0;
-            HIP_TRY(hipMalloc((void **)&x->d_chunk_slabs, need * sizeof(float)));
-            x->chunk_slab_floats = need;
-        }
+    x->plan = plan_chunks(s, d, p, chunks, (size_t)s->tuning.slab_budget_mb << 20, false);
+    if (x->chunk_bytes < x->plan.bytes) {
+        if (x->d_chunks) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(x->d_chunks); }
+        x->d_chunks = nullptr; x->chunk_bytes = 0;
+        HIP_TRY(hipMalloc((void **)&x->d_chunks, x->plan.bytes));
+        x->chunk_bytes = x->plan.bytes;
     }
     *out = x;
     return CRT_OK;
@@ -884,10 +919,10 @@ static void add_stats(crt_stats *stats, const unsigned long long c[32], float ke
 
 static void print_sections(const unsigned long long c[32])
 { // tuning aid: where the waves of the instrumented kernel spend their time
-    static const char *const name[9] = { "votes", "hit+shade", "store+fetch", "philox", "scatter", "camera", "spheres+root box", "node steps", "leaf steps" };
+    static const char *const name[10] = { "votes", "hit+shade", "store+fetch", "philox", "scatter", "camera", "spheres+root box", "node steps", "leaf steps", "ring sums" };
     unsigned long long total = 0;
-    for (int k = 0; k < 9; k++) total += c[18 + k];
-    for (int k = 0; k < 9; k++) fprintf(stderr, "crt sections: %-17s %5.1f %%\n", name[k], total ? 100.0 * (double)c[18 + k] / (double)total : 0.0);
+    for (int k = 0; k < 10; k++) total += c[18 + k];
+    for (int k = 0; k < 10; k++) fprintf(stderr, "crt sections: %-17s %5.1f %%\n", name[k], total ? 100.0 * (double)c[18 + k] / (double)total : 0.0);
 }
 
 template <class T>
@@ -914,7 +949,7 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
     const size_t rgb_floats = output_floats(p);
     StreamScratch *x = nullptr;
     std::unique_lock<std::mutex> lock(s->mutex); // held while the frame is enqueued, not while the host waits for it
-    if ((rc = acquire_scratch(d, stream, chunks, rgb_floats, &x))) return rc;
+    if ((rc = acquire_scratch(s, d, stream, p, chunks, &x))) return rc;
 
     const bool stated = (p->flags & CRT_OUT_DEVICE) != 0;
     const bool rgb_on_device = stated || is_device_pointer(out_rgb);
@@ -935,7 +970,7 @@ extern "C" int crt_render(const crt_scene *cs, const crt_camera *cam, const crt_
         if (p->tile_ranks > 1) HIP_TRY(hipMemcpyAsync(d_ids, out_ids, npix * sizeof(int), hipMemcpyHostToDevice, stream));
     }
 
-    if ((rc = enqueue_render(s, d, cam, p, chunks, d_rgb, d_ids, x->d_counters, x->d_chunk_slabs, x->ev0, x->ev1, stream, &x->split))) return rc;
+    if ((rc = enqueue_render(s, d, cam, p, chunks, d_rgb, d_ids, x->d_counters, x->d_chunks, x->plan, x->ev0, x->ev1, stream, &x->split))) return rc;
     HIP_TRY(hipEventRecord(x->ev_done, stream));
     x->recorded = true;
 
@@ -969,15 +1004,16 @@ extern "C" int crt_render_noalloc(const crt_scene *cs, const crt_camera *cam, co
     const DeviceScene &d = s->dev[0];
     unsigned char *scratch = (unsigned char *)noalloc_scratch_ptr(d.device);
     if (!scratch) return fail(CRT_ERR_HIP, "crt_render_noalloc: the static scratch of this device was not set up at commit");
-    const size_t rgb_floats = output_floats(p);
-    if (chunks > 1 && (uint64_t)chunk_slab_floats(rgb_floats, chunks) * sizeof(float) > (uint64_t)CRT_NOALLOC_SLAB_BYTES)
-        return fail(CRT_ERR_LIMIT, "crt_render_noalloc: output floats (pixels rounded up to a multiple of 64) x sample_chunks x 4 exceeds the static scratch (CRT_NOALLOC_SLAB_BYTES = 32 MiB); "
-                                   "use fewer sample_chunks (1 needs no slab) or crt_render");
+    // sample chunks must fit the static scratch: as slabs, else as rings with fewer blocks in flight per wave if need be (at least two)
+    const ChunkPlan plan = plan_chunks(s, d, p, chunks, (size_t)CRT_NOALLOC_SLAB_BYTES, true);
+    if (plan.mode == CM_RING && plan.ring_slots == 0)
+        return fail(CRT_ERR_LIMIT, "crt_render_noalloc: the sample-chunk ring (persistent waves x 2 blocks x units per block x 12 bytes; a block is at least one pixel's "
+                                   "spp samples) exceeds the static scratch (CRT_NOALLOC_SLAB_BYTES = 32 MiB): use sample_chunks <= 1 (no scratch) or crt_render");
     HIP_TRY(hipSetDevice(d.device));
     hipStream_t stream = (hipStream_t)p->stream;
     unsigned long long *d_counters = (unsigned long long *)scratch;
-    float *d_slabs = (float *)(scratch + CRT_NOALLOC_SLAB_OFFSET);
-    if ((rc = enqueue_render(s, d, cam, p, chunks, out_rgb, out_ids, d_counters, d_slabs, nullptr, nullptr, stream, &d.noalloc_split))) return rc; // (the second stream and its events were made at commit)
+    float *d_chunks = (float *)(scratch + CRT_NOALLOC_SLAB_OFFSET);
+    if ((rc = enqueue_render(s, d, cam, p, chunks, out_rgb, out_ids, d_counters, d_chunks, plan, nullptr, nullptr, stream, &d.noalloc_split))) return rc; // (the second stream and its events were made at commit)
     if (out_rays) HIP_TRY(hipMemcpyAsync(out_rays, d_counters, sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
     return CRT_OK;
 }
@@ -1136,8 +1172,8 @@ extern "C" int crt_render_multi(const crt_scene *cs, const crt_camera *cam, cons
         if (mode == CRT_MULTI_TILE) { q[r].tile_rank = r; q[r].tile_ranks = n; q[r].flags |= CRT_OUT_COMPACT; }
         else {
             q[r].spp = p->spp / n; q[r].sample_offset = p->sample_offset + r * (p->spp / n); q[r].flags |= CRT_OUT_ACCUM;
-            uint32_t c = chunks;
-            while (c > 1 && q[r].spp % c) c >>= 1; // the rank's share of the samples must still divide into the chunks
+            uint32_t c = chunks == p->spp ? q[r].spp : chunks; // one sample per unit stays one sample per unit
+            while (c > 1 && q[r].spp % c) c--;                 // else the rank's share of the samples must still divide into the chunks
             q[r].sample_chunks = c;
         }
     }
@@ -1198,9 +1234,9 @@ extern "C" int crt_render_multi(const crt_scene *cs, const crt_camera *cam, cons
         if (out_ids) HIP_TRY(hipStreamWaitEvent(st, m.fork, 0));
         // this set's previous frame (two frames ago): its parts on the root have been consumed once that frame was complete
         if (m.done_recorded[set]) HIP_TRY(hipStreamWaitEvent(st, m.frame_done[set], 0));
-        if ((rc = acquire_scratch(s->dev[r], st, rank_chunks, part, &x[r]))) return rc;
+        if ((rc = acquire_scratch(s, s->dev[r], st, &q[r], rank_chunks, &x[r]))) return rc;
         q[r].stream = st;
-        if ((rc = enqueue_render(s, s->dev[r], cam, &q[r], rank_chunks, k.d_local[set], d_ids, x[r]->d_counters, x[r]->d_chunk_slabs, x[r]->ev0, x[r]->ev1, st, &x[r]->split)))
+        if ((rc = enqueue_render(s, s->dev[r], cam, &q[r], rank_chunks, k.d_local[set], d_ids, x[r]->d_counters, x[r]->d_chunks, x[r]->plan, x[r]->ev0, x[r]->ev1, st, &x[r]->split)))
             return rc;
         HIP_TRY(hipEventRecord(x[r]->ev_done, st));
         x[r]->recorded = true;

@@ -11,6 +11,7 @@
 // The traversal stack is an LDS column per lane (stack[level][lane]: bank = lane, conflict free), with 16-bit entries where
 // the tree's references fit a short.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 
@@ -107,31 +108,89 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v)
     return v;
 }
 
-// renderer.h:36-37 + color.h:5-24: average, gamma, store (or the raw sum in accumulate mode)
-// chunk / first_sample: the part of the pixel's samples this lane rendered (sample chunks: RenderArgs.chunks > 1; then
-// the launcher has set RA_ACCUM and `out` is the chunk scratch, see finalize_chunks_kernel)
-// where pixel (or compact slot) px, chunk c goes in the chunk scratch, in units of 3 floats: [px / 64][c][px % 64]; with one
-// chunk (shift 0) this is px itself, the frame's own layout
-__device__ __forceinline__ size_t chunk_slot(uint32_t px, uint32_t chunk, uint32_t chunk_shift)
+// renderer.h:36-37 + color.h:5-24: average, gamma (or the raw sum in accumulate mode)
+__device__ __forceinline__ float finish_channel(float v, float spp, bool raw)
 {
-    return ((size_t)px << chunk_shift) | chunk;
+    if (raw) return v;
+    v = v / spp;
+    return v > 0 ? __builtin_sqrtf(v) : 0.0f;
+}
+// ... and store, for the kernels whose lanes sum their unit's samples themselves (RenderArgs.chunk_mode CM_WHOLE / CM_SLAB).
+// q = where the unit goes: the pixel (or compact slot), or with slabs (pixel or slot) * chunks + chunk -- then `out` is the
+// chunk scratch [pixel][chunk][3] and receives the raw chunk sum (finalize_chunks_kernel adds a pixel's chunk sums in chunk order).
+__device__ __forceinline__ void store_unit(const RenderArgs &ra, float *__restrict__ out, uint32_t q, f3 col)
+{
+    const bool raw = (ra.flags & RA_ACCUM) != 0 || ra.chunk_mode == CM_SLAB;
+    const size_t idx = q;
+    out[3 * idx + 0] = finish_channel(col.x, (float)ra.spp, raw);
+    out[3 * idx + 1] = finish_channel(col.y, (float)ra.spp, raw);
+    out[3 * idx + 2] = finish_channel(col.z, (float)ra.spp, raw);
 }
 
-__device__ __forceinline__ void store_pixel(const RenderArgs &ra, float *__restrict__ out, int *__restrict__ ids, uint32_t q, uint32_t pixel, f3 col,
-                                            int primary, uint32_t chunk = 0, uint32_t first_sample = 0, uint32_t nsamples = 0xFFFFFFFFu)
+// pixel slot (8x8-tile order over this rank's tiles) -> column | row << 16; false: outside the image (ragged last tile column / row)
+__device__ __forceinline__ bool slot_pixel(const RenderArgs &ra, uint32_t slot, uint32_t &ij)
 {
-    f3 o = col;
-    if (!(ra.flags & RA_ACCUM)) {
-        o = div3(col, (float)ra.spp);
-        o.x = o.x > 0 ? __builtin_sqrtf(o.x) : 0.0f;
-        o.y = o.y > 0 ? __builtin_sqrtf(o.y) : 0.0f;
-        o.z = o.z > 0 ? __builtin_sqrtf(o.z) : 0.0f;
+    const uint32_t tile = (slot >> 6) * ra.tile_ranks + ra.tile_rank, l = slot & 63u;
+    // tile / tiles_x by the host's floor(2^32 / tiles_x): at most one too small
+    uint32_t ty = __umulhi(tile, ra.tiles_x_magic), tx = tile - ty * ra.tiles_x;
+    if (tx >= ra.tiles_x) { tx -= ra.tiles_x; ty++; }
+    const uint32_t i = tx * 8u + (l & 7u), j = ty * 8u + (l >> 3);
+    ij = i | (j << 16);
+    return i < ra.width && j < ra.height; // renderer.h:22
+}
+
+// Sample chunks (RenderArgs.chunks = n > 1): the work unit is ONE SAMPLE of a pixel, and the units of a block of 2^group_shift
+// pixels (x spp samples) are rendered by the lanes of ONE wave, which also adds them up: every finished sample goes to the wave's
+// own ring in device memory (ring_slots blocks of block_units x 12 bytes, small enough to stay in the L2;
+// lanes of one wave see each other's stores without any cache maintenance: a wave's vector memory operations reach its L1 in
+// order), a count per ring slot says when a block is complete, and the wave then adds each pixel's n chunk sums IN CHUNK ORDER,
+// STARTING FROM 0 -- with one sample per chunk the float operations of the reference's own loop (renderer.h:26-32), so the frame
+// is the sequential sum bit for bit -- and writes the finished pixels.  One lane per (pixel of the block, colour channel): the
+// three chains of a pixel are independent, a chain is n dependent additions.  No slabs in HBM, no second kernel.
+typedef __attribute__((address_space(1))) float *global_f32_ptr;
+// `done`: the ring slots whose blocks are complete (at least one).  Their pixels' chains are dealt to the lanes together -- the
+// pass costs the same instructions whether 6 or 60 lanes take part, so the caller lets complete blocks collect (RenderArgs.ring_batch).
+__device__ __forceinline__ void finalize_ring_blocks(const RenderArgs &ra, float *__restrict__ out, global_f32_ptr wring, uint32_t done,
+                                                     const uint32_t *ring_block, uint32_t lane)
+{
+    unsigned long long list = 0; // the slots of the complete blocks, four bits each
+    uint32_t nblocks = 0;
+    for (uint32_t m = done; m; m &= m - 1u, nblocks++) list |= (unsigned long long)__builtin_ctz(m) << (4u * nblocks);
+    const uint32_t chains = (3u << ra.group_shift) * nblocks, n = ra.chunks;
+    const bool raw = (ra.flags & RA_ACCUM) != 0;
+    for (uint32_t idx = lane; idx < ((chains + 63u) & ~63u); idx += 64u) { // (wave-uniform trip count)
+        if (idx < chains) {
+            const uint32_t pix = __umulhi(idx, 0x55555556u), c = idx - 3u * pix; // idx / 3 for idx < 2^31: pixel of the pass, colour channel
+            const uint32_t rs = (uint32_t)(list >> (4u * (pix >> ra.group_shift))) & 15u, g = pix & ((1u << ra.group_shift) - 1u);
+            const uint32_t slot = (ring_block[rs] << ra.group_shift) + g;
+            uint32_t ij;
+            const bool inside = slot_pixel(ra, slot, ij);
+            global_f32_ptr src = wring + (rs * ra.block_units + g * ra.spp) * 3u + c; // the pixel's samples, 3 floats apart
+            float acc = 0.0f; // renderer.h:26
+#ifdef CRT_RING_NOSUM // timing probe: what the additions and their loads cost (the frame is wrong)
+            acc = src[0];
+#else
+            if (ra.chunk_spp == 1u) { // one sample per chunk: the reference's own loop (a chunk sum 0 + s is s: the sum so far is never -0)
+                uint32_t k = 0;
+                for (; k + 8u <= n; k += 8u, src += 24) { // eight loads in flight, their offsets in the instructions
+                    const float s0 = src[0], s1 = src[3], s2 = src[6], s3 = src[9], s4 = src[12], s5 = src[15], s6 = src[18], s7 = src[21];
+                    acc = acc + s0; acc = acc + s1; acc = acc + s2; acc = acc + s3; acc = acc + s4; acc = acc + s5; acc = acc + s6; acc = acc + s7;
+                }
+                for (; k < n; k++, src += 3) acc = acc + src[0];
+            } else {
+                for (uint32_t j = 0; j < n; j++, src += 3u * ra.chunk_spp) {
+                    float chunk_sum = 0.0f;
+#pragma unroll 4
+                    for (uint32_t k = 0; k < ra.chunk_spp; k++) chunk_sum = chunk_sum + src[3u * k];
+                    acc = acc + chunk_sum;
+                }
+            }
+#endif
+            const size_t px = (ra.flags & RA_COMPACT) ? slot : (size_t)(ij >> 16) * ra.width + (ij & 0xFFFFu);
+            if (inside) out[3 * px + c] = finish_channel(acc, (float)ra.spp, raw);
+            else if (ra.flags & RA_COMPACT) out[3 * px + c] = 0.0f;
+        }
     }
-    const uint32_t px = (ra.flags & RA_COMPACT) ? q : pixel;
-    const size_t idx = chunk_slot(px, chunk, ra.chunk_shift);
-    out[3 * idx + 0] = o.x; out[3 * idx + 1] = o.y; out[3 * idx + 2] = o.z;
-    const uint32_t n = nsamples == 0xFFFFFFFFu ? ra.spp : nsamples, first = ra.sample_offset + first_sample;
-    if (ids && ra.ids_sample >= first && ra.ids_sample - first < n) ids[pixel] = primary;
 }
 
 __device__ __forceinline__ int popc64(unsigned long long m) { return __popcll(m); }
@@ -246,7 +305,7 @@ __device__ __forceinline__ void trav_inner_lds_sorted(lds_q4_ptr nodes, const Si
 // Section clock of the instrumented kernel (CRT_COUNT_WORK): shader-clock ticks a wave spends in each part of the loop
 template <bool ON>
 struct SectionClock {
-    unsigned long long sum[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, last = 0;
+    unsigned long long sum[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, last = 0;
     __device__ __forceinline__ void start() { if constexpr (ON) { __builtin_amdgcn_sched_barrier(0); last = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } }
     template <int K>
     __device__ __forceinline__ void lap()
@@ -263,7 +322,7 @@ struct SectionClock {
 #define CRT_LAP(clk, k) (clk).template lap<k>()
 
 // Lane phases while not walking (a lane walks the BVH iff tv.cur != CRT_BVH_NONE)
-enum { P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 };
+enum { P_STARVED = -1, P_DONE = 0, P_FETCH = 1, P_NEW = 2, P_HIT = 3 }; // (P_STARVED: needs a work unit while the wave's sample-chunk ring is full)
 
 // render_kernel: persistent waves, each on its own (W = 1: one per workgroup; W = 4: four per workgroup that share an LDS
 // copy of the top of the tree and otherwise never meet).  A lane owns one work unit at a time: a pixel, its samples summed
@@ -320,7 +379,7 @@ static_assert(CRT_WORK_STRIPES == 64u, "the order in which a wave visits the blo
 #endif
 extern __shared__ int lds_dynamic[]; // render_kernel_dyn's stacks (DYNAMIC = 1) or node copy + stacks (DYNAMIC = 2), see there
 // WHOLE: the launcher has checked that the whole node array is in the LDS copy (sc.nnodes <= NC): no device-memory node step exists
-template <bool COUNT_WORK, int SD, bool SS, int W, int NC, int DYNAMIC = 0, bool WHOLE = false>
+template <bool COUNT_WORK, int SD, bool SS, int W, int NC, bool RING, int DYNAMIC = 0, bool WHOLE = false>
 __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *__restrict__ out,
                                             int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
@@ -371,10 +430,22 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
 
     uint32_t q = NO_PIXEL, ij = 0, pixel = 0; // ij = column | row << 16 of the pixel (both < 65536)
     f3 col = mk3(0.0f, 0.0f, 0.0f);
-    int primary = -1; // primitive id of the primary hit of sample `ids_sample`, if this unit renders that sample
     int phase = P_FETCH;
     uint32_t rays_wave = 0;
-    uint32_t blk_next = 0, blk_end = 0; // the wave's block of work units [blk_next, blk_end) (wave-uniform)
+    uint32_t blk_next = 0, blk_end = 0; // the wave's current block of work units: units [blk_next, blk_end) are still to hand out (wave-uniform)
+    uint32_t blk_block = 0; // ... and its index in the frame
+    // Sample chunks: the ring of blocks in flight (see finalize_ring_block).  ring_block[r] (LDS, touched once per block) = frame index
+    // of the block in slot r; lane r of ring_count = units of it that are finished (a lane register read with v_readlane and written with a
+    // select: an LDS round trip per shade phase was measurable).  Two scalar registers (the kernel has none to
+    // spare): ring_state = slots without a block (bits 0..15) | slots whose block is complete and waits to be added up (16..31);
+    // ring_aux = slot of the wave's current block (bits 0..3) | lanes that need a unit while the ring is full (8..14): those wait
+    // in P_STARVED without counting as ready -- they would keep the wave in the shade phase while the walks that could complete a
+    // block never advance -- and the others vote as a smaller wave.
+    __shared__ uint32_t ring_block_all[W][16];
+    const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave); // (a scalar: no lane register for it)
+    uint32_t *ring_block = ring_block_all[wave_s];
+    uint32_t ring_count = 0;
+    uint32_t ring_state = RING ? (1u << ra.ring_slots) - 1u : 0u, ring_aux = 0;
     uint32_t stripe = home, stripes_left = CRT_WORK_STRIPES; // counter in use, counters not yet seen empty
     uint32_t samples = 0, depth = 0; // samples = index of the current sample | samples still to do << 16 (both <= 65535: crt_render's limits)
     Path p;
@@ -383,31 +454,53 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
     hit.t = FLT_MAX; hit.code = -1; hit.mat = 0; hit.rank = 0; hit.near_tie = false;
     Trav tv;
     tv.idir = tv.ood = mk3(0.0f, 0.0f, 0.0f); tv.shift = 0.0f; tv.hi = 0.0f; tv.cur = NONE;
-    const int threshold = (int)ra.sched_threshold;
+    const int threshold_all = (int)ra.sched_threshold;
     uint32_t wc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }; // schedule counters, lane 0 only (COUNT_WORK)
     unsigned long long t_start = 0;
     if constexpr (COUNT_WORK) t_start = wall_clock64(); // 100 MHz
-    SectionClock<COUNT_WORK> clk; // [0] votes [1] hit + shade [2] store + fetch [3] Philox [4] scatter [5] camera [6] spheres + root box [7] node steps [8] leaf steps
+    SectionClock<COUNT_WORK> clk; // [0] votes [1] hit + shade [2] store + fetch [3] Philox [4] scatter [5] camera [6] spheres + root box [7] node steps [8] leaf steps [9] adding up complete ring blocks
     clk.start();
 
     // Every pass of this loop makes progress (a shade phase retires or starts a path segment for every ready lane, a walk
     // phase advances at least one walk by a step), so it ends; the trip counter turns a scheduling bug into a flag the
     // host reports (counters[CRT_COUNTER_GUARD], checked by crt_render) instead of a wave that never leaves the GPU.
     bool guard_tripped = false;
+    const uint32_t guard_limit = ra.guard_passes;
     for (uint32_t guard = 0;; guard++) {
+        // sample chunks: complete blocks are added up and written out here, where few registers are live -- when ring_batch of them
+        // have collected, or when the ring has no free slot left; their slots are free again and the lanes that waited may ask again
+        if (RING && __builtin_expect((ring_state >> 16) != 0u && (popc64(ring_state >> 16) >= (int)ra.ring_batch || (ring_state & 0xFFFFu) == 0u), 0)) {
+            CRT_LAP(clk, 0);
+            const RenderArgs rak = load_kernel_arg<RenderArgs>(offsetof(KernelArgsLayout, ra));
+            const global_f32_ptr wring = (global_f32_ptr)(uintptr_t)((uint64_t)rak.ring_lo | (uint64_t)rak.ring_hi << 32) +
+                                         (size_t)(rak.ring_wave_base + blockIdx.x * W + wave_s) * rak.ring_slots * rak.block_units * 3u;
+            const uint32_t done = ring_state >> 16;
+            finalize_ring_blocks(rak, out, wring, done, ring_block, lane);
+            ring_count = (done >> lane) & 1u ? 0u : ring_count;
+            ring_state = (ring_state & 0xFFFFu) | done; // done -> free
+            ring_aux &= 0xFu;                            // nobody starved
+            phase = phase == P_STARVED ? P_FETCH : phase;
+            CRT_LAP(clk, 9);
+        }
         const bool walking = tv.cur != NONE;
         // (every lane is alive here, so masks of single comparisons can be combined as scalars; a ballot of `a && b` would
         // first write the bool to a register and compare it again)
-        const unsigned long long walk_mask = __ballot(walking), active_mask = ~walk_mask & __ballot(phase != P_DONE);
+        const unsigned long long walk_mask = __ballot(walking), active_mask = ~walk_mask & __ballot(phase > P_DONE);
         const int nwalk = popc64(walk_mask);
         const int nready = popc64(active_mask);
-        if (nready + nwalk == 0) break;
-        if (guard >= CRT_GUARD_PASSES) { guard_tripped = true; break; }
+        if (nready + nwalk == 0) {
+            // Starved lanes imply a full ring, i.e. units in flight on lanes that are ready or walking, so there are none left here;
+            // if there ever were, the frame is incomplete and the host is told (below, behind the loop).  (No `continue` that would wake them instead: a
+            // second back edge makes the compiler keep the loop's scalar state in lane registers -- 23 spills and half the speed.)
+            break;
+        }
+        if (guard >= guard_limit) { guard_tripped = true; break; }
+        const int threshold = RING ? max(threshold_all - (int)(ring_aux >> 8), 1) : threshold_all;
         if (nready >= threshold || nwalk == 0) {
             // ================================ phase A ================================
             if constexpr (COUNT_WORK) { if (lane == 0) { wc[0]++; wc[1] += nready; } }
             CRT_LAP(clk, 0);
-            const bool active = !walking && phase != P_DONE;
+            const bool active = !walking && phase > P_DONE;
             // The shade phase reads the scene description (root box, sphere list, shading records, counts) from the kernel
             // arguments where it needs it, like the camera: kept in scalar registers for the whole kernel it does not fit
             // beside the walk's state and comes back through ~30 v_readlane per phase.  The walk itself only needs the
@@ -434,7 +527,8 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
                     const Shade m = load_global(sck.shades, (size_t)mat); // issued together with the primitive fetch below: one memory round trip per hit
                     sf = surface_at<SS>(sck, code, p.o, p.d, t);
                     cnt.shade();
-                    if (depth == 0 && ra.sample_offset + (samples & 0xFFFFu) == ra.ids_sample) primary = sf.prim;
+                    // (primary-hit ids: -1 was written when the unit that holds sample ids_sample was fetched; its first hit says otherwise)
+                    if (depth == 0 && ra.sample_offset + (samples & 0xFFFFu) == ra.ids_sample && ids) ids[pixel] = sf.prim;
                     m_type = m.type; m_param = m.param;
                     colour = texture_value(m, sf.point);
                     const f3 e = emitted(m_type, colour); // camera.h:73-74
@@ -443,9 +537,12 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
                     want_scatter = scatters(m_type) && depth + 1 < ra.max_depth;
                 }
                 if (!want_scatter) { // path over: renderer.h:31
-                    col = col + p.color;
-                    samples += 1u - 0x10000u; // next index, one fewer to do
-                    phase = samples >= 0x10000u ? P_NEW : P_FETCH;
+                    if constexpr (RING) phase = P_FETCH; // (one sample per unit: p.color goes to the ring)
+                    else {
+                        col = col + p.color;
+                        samples += 1u - 0x10000u; // next index, one fewer to do
+                        phase = samples >= 0x10000u ? P_NEW : P_FETCH;
+                    }
                 }
             }
             CRT_LAP(clk, 1);
@@ -453,25 +550,39 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
             // Atomics on one address are served ~5 ns apart device-wide and every wave waits its turn (measured: 2 M per
             // frame cost 10 ms), hence blocks, and several counters.
             const bool fetching = active && phase == P_FETCH;
-            const unsigned long long fm = active_mask & __ballot(phase == P_FETCH);
+            const unsigned long long fm = __ballot(phase == P_FETCH); // (a lane that needs a unit is not walking; lanes that found the ring full ask again)
             if (fm) {
                 const RenderArgs rak = load_kernel_arg<RenderArgs>(offsetof(KernelArgsLayout, ra)); // the frame geometry is only needed here
-                const uint32_t chunk_spp = rak.spp >> rak.chunk_shift, chunk_mask = rak.chunks - 1u;
-                // q is the work index: (pixel slot << chunk_shift) | chunk
-                if (fetching && q != NO_PIXEL) {
-                    const uint32_t chunk = q & chunk_mask;
-                    store_pixel(rak, out, ids, q >> rak.chunk_shift, pixel, col, primary, chunk, chunk * chunk_spp, chunk_spp);
-                }
-                // Units come in blocks of 2^fetch_shift from CRT_WORK_STRIPES counters 256 B apart; block g of counter k
-                // is global block g * stripes + k, so all counters advance through the frame in raster order together.
-                const uint32_t total = rak.local_pixels << rak.chunk_shift;
+                constexpr bool ring_mode = RING; // (the launcher picks the kernel: RING <=> rak.chunks > 1)
+                const uint32_t block_units = rak.block_units;
+                if (ring_mode) {
+                    // q = ring slot << 16 | index of the unit in its block; the unit's raw sum goes to the wave's ring
+                    const global_f32_ptr wring = (global_f32_ptr)(uintptr_t)((uint64_t)rak.ring_lo | (uint64_t)rak.ring_hi << 32) +
+                                                 (size_t)(rak.ring_wave_base + blockIdx.x * W + wave_s) * rak.ring_slots * block_units * 3u;
+                    const bool done = fetching && q != NO_PIXEL;
+                    if (done && pixel != NO_PIXEL) { // (pixel == NO_PIXEL: a unit outside the image, only counted)
+                        const global_f32_ptr dst = wring + ((q >> 16) * block_units + (q & 0xFFFFu)) * 3u;
+                        dst[0] = p.color.x; dst[1] = p.color.y; dst[2] = p.color.z;
+                    }
+                    // count the finished units per ring slot (they belong to one or two blocks, rarely more)
+                    unsigned long long dm = __ballot(done);
+                    while (dm) {
+                        const uint32_t rs = (uint32_t)__builtin_amdgcn_readlane((int)(q >> 16), __builtin_ctzll(dm));
+                        const unsigned long long m = dm & __ballot((q >> 16) == rs);
+                        dm &= ~m;
+                        const uint32_t count = (uint32_t)__builtin_amdgcn_readlane((int)ring_count, (int)rs) + (uint32_t)popc64(m);
+                        ring_count = lane == rs ? count : ring_count;
+                        if (count == block_units) ring_state |= 0x10000u << rs; // added up at the top of the main loop
+                    }
+                } else if (fetching && q != NO_PIXEL) store_unit(rak, out, q, col);
+                // Units come in blocks of block_units (2^group_shift pixels x chunks) from CRT_WORK_STRIPES counters 256 B apart
                 const uint32_t n_need = (uint32_t)popc64(fm), left = blk_end - blk_next, rk = (uint32_t)lane_rank(fm);
-                uint32_t fresh = total, fresh_end = total;
-                if (n_need > left) {
+                uint32_t fresh_units = 0, fresh_block = 0, fresh_rs = 0;
+                if (n_need > left && (!ring_mode || (ring_state & 0xFFFFu) != 0u)) {
                     const int leader = __builtin_ctzll(fm);
                     // blocks_per_stripe = 0: block b of counter k is global block b * stripes + k (all counters walk the frame
                     // together); else counter k owns the contiguous blocks [k * bps, (k + 1) * bps) (a band of the frame)
-                    const uint32_t bps = rak.blocks_per_stripe, fetch_block = 1u << rak.fetch_shift, nblocks = (total + fetch_block - 1u) >> rak.fetch_shift;
+                    const uint32_t bps = rak.blocks_per_stripe, nblocks = rak.nblocks;
                     while (stripes_left > 0) {
                         // blocks of this counter
                         const uint32_t mine = bps ? (nblocks > stripe * bps ? (nblocks - stripe * bps < bps ? nblocks - stripe * bps : bps) : 0u)
@@ -480,8 +591,12 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
                         if ((int)lane == leader) b = atomicAdd(work + stripe * 64u, 1u);
                         b = (uint32_t)__builtin_amdgcn_readlane((int)b, leader);
                         if (b < mine) {
-                            fresh = (bps ? stripe * bps + b : b * CRT_WORK_STRIPES + stripe) << rak.fetch_shift;
-                            fresh_end = total - fresh > fetch_block ? fresh + fetch_block : total;
+                            fresh_block = bps ? stripe * bps + b : b * CRT_WORK_STRIPES + stripe;
+                            fresh_units = block_units;
+                            if (rak.chunk_mode == CM_WHOLE) { // (the last block of a whole-pixel frame may be short; with sample chunks a block is at most 64 pixels, and a rank's pixel slots are a multiple of 64)
+                                const uint32_t behind = rak.local_pixels - fresh_block * block_units;
+                                fresh_units = behind < block_units ? behind : block_units;
+                            }
                             break;
                         }
                         // This counter is used up.  The wave that is the first to see that (b == mine) counts it in `used_up`;
@@ -499,41 +614,62 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
                         const uint32_t seen = CRT_WORK_STRIPES - stripes_left, s0 = home;
                         stripe = ((((s0 >> 3) + seen) & 7u) << 3) | (((s0 & 7u) + (seen >> 3)) & 7u);
                     }
+                    if (ring_mode && fresh_units) { // the new block takes a free ring slot (its count is 0)
+                        fresh_rs = (uint32_t)__builtin_ctz(ring_state);
+                        ring_state &= ring_state - 1u;
+                        ring_block[fresh_rs] = fresh_block;
+                    }
                 }
-                const uint32_t unit = rk < left ? blk_next + rk : fresh + (rk - left); // >= fresh_end: nothing for this lane now
-                const bool got = rk < left || unit < fresh_end;
+                // the lane's unit: index k in the wave's current block, or in the fresh one
+                const bool from_current = rk < left;
+                const uint32_t k = from_current ? blk_next + rk : rk - left;
+                const bool got = from_current || k < fresh_units;
+                const uint32_t block = from_current ? blk_block : fresh_block, rs = from_current ? ring_aux & 0xFu : fresh_rs;
                 if (n_need > left) {
-                    const uint32_t used = fresh + (n_need - left);
-                    blk_next = used < fresh_end ? used : fresh_end;
-                    blk_end = fresh_end;
+                    if (fresh_units) {
+                        const uint32_t used = n_need - left;
+                        blk_next = used < fresh_units ? used : fresh_units;
+                        blk_end = fresh_units; blk_block = fresh_block;
+                        ring_aux = (ring_aux & ~0xFu) | fresh_rs;
+                    } else blk_next = blk_end;
                 } else blk_next += n_need;
                 const bool exhausted = stripes_left == 0;
+                if (ring_mode && !exhausted && n_need > left + fresh_units) {
+                    ring_aux += (n_need - left - fresh_units) << 8; // lanes that will wait for a ring slot
+                    if constexpr (COUNT_WORK) { if (lane == 0) wc[3] += n_need - left - fresh_units; } // (crt_stats.sched[3])
+                }
                 if (fetching) {
                     // Raster tile order on purpose.  Measured slower: fetching one pixel ahead (+15 %: a lane then holds a
                     // pixel hostage at the end of the frame), the tiles over the mesh first (+14 %), spread evenly (+5 %),
                     // or started at the mesh's first tile row (+11 %): DESIGN.md section 7.
-                    q = unit;
-                    if (!got) { q = NO_PIXEL; if (exhausted) phase = P_DONE; } // else: asks again in the next phase A
+                    q = NO_PIXEL;
+                    if (!got) phase = exhausted ? P_DONE : ring_mode ? P_STARVED : P_FETCH; // (whole pixels: the block was short, asks again in the next phase A)
                     else {
-                        const uint32_t slot = q >> rak.chunk_shift, chunk = q & chunk_mask;
-                        const uint32_t tile = (slot >> 6) * rak.tile_ranks + rak.tile_rank, l = slot & 63u;
-                        // tile / tiles_x by the host's floor(2^32 / tiles_x): at most one too small
-                        uint32_t ty = __umulhi(tile, rak.tiles_x_magic), tx = tile - ty * rak.tiles_x;
-                        if (tx >= rak.tiles_x) { tx -= rak.tiles_x; ty++; }
-                        const uint32_t i = tx * 8u + (l & 7u), j = ty * 8u + (l >> 3);
-                        ij = i | (j << 16);
-                        if (i < rak.width && j < rak.height) { // renderer.h:22
-                            pixel = j * rak.width + i;      // renderer.h:24
-                            samples = (chunk * chunk_spp) | (chunk_spp << 16);
-                            col = mk3(0.0f, 0.0f, 0.0f);
-                            primary = -1;
-                            phase = P_NEW;
-                        } else { // outside the image (ragged last tile column / row): nothing to render, fetch again next time
-                            if (rak.flags & RA_COMPACT) {
-                                const size_t z = chunk_slot(slot, chunk, rak.chunk_shift);
-                                out[3 * z + 0] = 0.0f; out[3 * z + 1] = 0.0f; out[3 * z + 2] = 0.0f;
+                        // unit k of a block = part k % per_pixel of the block's pixel k / per_pixel: one sample of spp (ring), one chunk of
+                        // n (slabs), the pixel itself (k < 65536, per_pixel < 65536: exact with ceil(2^32 / per_pixel))
+                        const uint32_t g = rak.per_pixel > 1u ? __umulhi(k, rak.per_pixel_magic) : k, part = k - g * rak.per_pixel;
+                        const uint32_t slot = (block << rak.group_shift) + g;
+                        const bool inside = slot_pixel(rak, slot, ij);
+                        if (inside) {
+                            pixel = (ij >> 16) * rak.width + (ij & 0xFFFFu); // renderer.h:24
+                            if constexpr (RING) {
+                                samples = part;
+                                if (ids && ra.sample_offset + samples == ra.ids_sample) ids[pixel] = -1; // until the sample's first hit says otherwise
+                                q = (rs << 16) | k;
+                            } else {
+                                const uint32_t first = part * rak.chunk_spp;
+                                samples = first | (rak.chunk_spp << 16);
+                                col = mk3(0.0f, 0.0f, 0.0f);
+                                if (ids && ra.ids_sample - (ra.sample_offset + first) < rak.chunk_spp) ids[pixel] = -1; // (unsigned: also false below the unit's first sample)
+                                q = ((rak.flags & RA_COMPACT) ? slot : pixel) * rak.per_pixel + part;
                             }
-                            q = NO_PIXEL;
+                            phase = P_NEW;
+                        } else if (ring_mode) { // outside the image: nothing to render, but the unit counts for its block (next phase A)
+                            pixel = NO_PIXEL;
+                            q = (rs << 16) | k;
+                        } else if (rak.flags & RA_COMPACT) { // (a unit outside the image: its place in the compact list is cleared, the lane fetches again next time)
+                            const size_t z = (size_t)slot * rak.per_pixel + part;
+                            out[3 * z + 0] = 0.0f; out[3 * z + 1] = 0.0f; out[3 * z + 2] = 0.0f;
                         }
                     }
                 }
@@ -629,6 +765,13 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
         }
     }
 
+    if (RING && (ring_state >> 16) != 0u) { // the complete blocks that were still collecting
+        const RenderArgs rak = load_kernel_arg<RenderArgs>(offsetof(KernelArgsLayout, ra));
+        const global_f32_ptr wring = (global_f32_ptr)(uintptr_t)((uint64_t)rak.ring_lo | (uint64_t)rak.ring_hi << 32) +
+                                     (size_t)(rak.ring_wave_base + blockIdx.x * W + wave_s) * rak.ring_slots * rak.block_units * 3u;
+        finalize_ring_blocks(rak, out, wring, ring_state >> 16, ring_block, lane);
+    }
+    if (RING && __ballot(phase == P_STARVED)) guard_tripped = true; // (see the loop's exit)
     uint32_t refolds = 0;
     if constexpr (COUNT_WORK) refolds = wave_sum(cnt.refolds);
     if (lane == 0) {
@@ -656,16 +799,16 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
             atomicAdd(&counters[17], dt);
             atomicMax(&counters[10], dt);
 #pragma unroll
-            for (int k = 0; k < 9; k++) atomicAdd(&counters[18 + k], clk.sum[k]); // section clocks (CRT_PRINT_SECTIONS)
+            for (int k = 0; k < 10; k++) atomicAdd(&counters[18 + k], clk.sum[k]); // section clocks (CRT_PRINT_SECTIONS)
         }
     }
 }
 
-template <bool COUNT_WORK, int SD, bool SS, int W, int NC>
+template <bool COUNT_WORK, int SD, bool SS, int W, int NC, bool RING>
 __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
                                                                        int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
-    render_body<COUNT_WORK, SD, SS, W, NC>(sc, cam, ra, out, ids, counters);
+    render_body<COUNT_WORK, SD, SS, W, NC, RING>(sc, cam, ra, out, ids, counters);
 }
 
 // The 16-wave workgroup of a two-launch frame (launch_split).  With all of its LDS declared (one workgroup per CU) the compiler
@@ -681,13 +824,14 @@ template <int SD, int W, int NC, int DYNAMIC> constexpr size_t dynamic_lds_bytes
 {
     return (size_t)W * (SD + 2) * 64 * (SD == 14 ? sizeof(short) : sizeof(int)) + (DYNAMIC == 2 ? (size_t)CRT_LDS_NODE_BYTES * NC : 0); // (14 levels: 16-bit entries)
 }
-template <bool COUNT_WORK, int SD, bool SS, int W, int NC, int DYNAMIC, bool WHOLE = false>
+template <bool COUNT_WORK, int SD, bool SS, int W, int NC, bool RING, int DYNAMIC, bool WHOLE = false>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(CRT_WAVES_PER_EU, CRT_WAVES_PER_EU)))
 void render_kernel_dyn(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out, int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
-    render_body<COUNT_WORK, SD, SS, W, NC, DYNAMIC, WHOLE>(sc, cam, ra, out, ids, counters);
+    render_body<COUNT_WORK, SD, SS, W, NC, RING, DYNAMIC, WHOLE>(sc, cam, ra, out, ids, counters);
 }
 
+#ifdef CRT_WITH_POOL_KERNEL // experimental, measured and rejected: built with EXTRA_DEVFLAGS=-DCRT_WITH_POOL_KERNEL only
 // =========================================================================================================
 // render_pool_kernel: the same per-path operation sequence, scheduled over a pool of pixel contexts in LDS.
 //
@@ -954,7 +1098,7 @@ __global__ __launch_bounds__(64 * W) void render_pool_kernel(SceneView sc, Camer
                 if (need_pixel && ij != NO_PIXEL) { // pixel complete
                     const uint32_t i = ij & 0xFFFFu, j = ij >> 16;
                     const uint32_t tile = (j >> 3) * ra.tiles_x + (i >> 3);
-                    store_pixel(ra, out, nullptr, 64u * (tile / ra.tile_ranks) + ((j & 7u) << 3 | (i & 7u)), j * ra.width + i, pool.v3(CF_CX, c), -1);
+                    store_unit(ra, out, (ra.flags & RA_COMPACT) ? 64u * (tile / ra.tile_ranks) + ((j & 7u) << 3 | (i & 7u)) : j * ra.width + i, pool.v3(CF_CX, c));
                 }
             }
             // pixel queue: one atomic per batch
@@ -1039,6 +1183,8 @@ __global__ __launch_bounds__(64 * W) void render_pool_kernel(SceneView sc, Camer
     }
 }
 
+#endif // CRT_WITH_POOL_KERNEL
+
 // compact (rank-major, tile-major) -> row-major frame
 __global__ __launch_bounds__(64) void untile_kernel(const float *__restrict__ compact_all, uint32_t width, uint32_t height, uint32_t tiles_x,
                                                     uint32_t ntiles, uint32_t tile_ranks, uint32_t tiles_per_rank, float *__restrict__ out)
@@ -1081,30 +1227,19 @@ __global__ __launch_bounds__(256) void sum_frames_kernel(const float *__restrict
     out[k] = v;
 }
 
-// sample chunks: `slabs` is [block of 64 pixels][chunk][pixel in block][3].  The lanes that render a pixel's chunks sit in
-// the same wave and neighbouring pixels in the same or the next waves, so the 12-byte stores of a 48 KB block arrive close
-// together and its cache lines are complete before they leave the L2 (one frame-sized slab per chunk, the first layout,
-// wrote 1.8 bytes per payload byte); and thread r of a 192-thread block reads float r of every chunk row: 768 contiguous
-// bytes per block and chunk, no LDS -- this pass runs beside the next frame's render kernel, which leaves ~10 KB of a CU's LDS
-// free, and a staged version that needed 49 KB per block kept that kernel's workgroups off the CUs (+10 % per step).
-// out[pixel][ch] = finish((((0 + chunk 0) + chunk 1) + ...): the sum starts at 0 like the reference's pixel_color
-// (renderer.h:26), so with one sample per chunk the float operations are the sequential loop's own and the frame is
-// bit-identical to the whole-pixel one.
-__device__ __forceinline__ float finish_channel(float v, float spp, int raw)
-{
-    if (raw) return v;
-    v = v / spp;
-    return v > 0 ? __builtin_sqrtf(v) : 0.0f;
-}
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(32))) void finalize_chunks_kernel(const float *__restrict__ slabs, uint32_t chunk_shift, size_t npixels, float spp, int raw,
+// Sample chunks through slabs (RenderArgs.chunk_mode CM_SLAB): `slabs` is [pixel][chunk][3], the raw chunk sums of a pixel side by
+// side (the lanes that render them sit in one wave: with 64 chunks their twelve-byte stores fill 768 contiguous bytes).
+// out[pixel][ch] = finish((((0 + chunk 0) + chunk 1) + ...): the sum starts at 0 like the reference's pixel_color (renderer.h:26), so
+// with one sample per chunk the float operations are the sequential loop's own.  21 registers on purpose: the pass runs beside the
+// next frame's render kernel, in the 32 registers per SIMD lane that five 96-register waves leave free.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(32))) void finalize_chunks_kernel(const float *__restrict__ slabs, uint32_t chunks, size_t npixels, float spp, int raw,
                                                              float *__restrict__ out)
 {
     const size_t pixel = (size_t)blockIdx.x * 64u + threadIdx.x;
     if (pixel >= npixels) return;
-    const uint32_t chunks = 1u << chunk_shift;
-    const float *row = slabs + (pixel << chunk_shift) * 3u;
+    const float *row = slabs + pixel * chunks * 3u;
     float r = 0.0f, g = 0.0f, b = 0.0f;
-    if (chunk_shift >= 2u) { // four chunks = 48 bytes = three 16-byte loads (the row starts at a multiple of 48 bytes)
+    if ((chunks & 3u) == 0u) { // four chunks = 48 bytes = three 16-byte loads (the row starts at a multiple of 48 bytes)
         const v4f *q = reinterpret_cast<const v4f *>(row);
 #pragma unroll 1
         for (uint32_t c = 0; c < chunks; c += 4u, q += 3) {
@@ -1117,9 +1252,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(32))) void final
     } else {
         for (uint32_t c = 0; c < chunks; c++) { r = r + row[3u * c]; g = g + row[3u * c + 1u]; b = b + row[3u * c + 2u]; }
     }
-    out[3u * pixel + 0u] = finish_channel(r, spp, raw);
-    out[3u * pixel + 1u] = finish_channel(g, spp, raw);
-    out[3u * pixel + 2u] = finish_channel(b, spp, raw);
+    out[3u * pixel + 0u] = finish_channel(r, spp, raw != 0);
+    out[3u * pixel + 1u] = finish_channel(g, spp, raw != 0);
+    out[3u * pixel + 2u] = finish_channel(b, spp, raw != 0);
+}
+
+hipError_t launch_finalize_chunks(const float *slabs, uint32_t chunks, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream)
+{
+    const size_t npixels = n / 3;
+    const uint32_t blocks = (uint32_t)((npixels + 63) / 64);
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(finalize_chunks_kernel, dim3(blocks), dim3(64), 0, stream, slabs, chunks, npixels, (float)spp, raw ? 1 : 0, out);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1159,17 +1303,6 @@ void *noalloc_scratch_ptr(int device)
     return g_scratch_ptr[device];
 }
 
-hipError_t launch_finalize_chunks(const float *slabs, uint32_t chunks, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream)
-{
-    uint32_t shift = 0;
-    while ((1u << shift) < chunks) shift++;
-    const size_t npixels = n / 3;
-    const uint32_t blocks = (uint32_t)((npixels + 63) / 64);
-    if (blocks == 0) return hipSuccess;
-    hipLaunchKernelGGL(finalize_chunks_kernel, dim3(blocks), dim3(64), 0, stream, slabs, shift, npixels, (float)spp, raw ? 1 : 0, out);
-    return hipGetLastError();
-}
-
 hipError_t launch_sum_frames(const float *frames, uint32_t count, size_t n, uint32_t spp, bool raw, float *out, hipStream_t stream)
 {
     const uint32_t blocks = (uint32_t)((n + 255) / 256);
@@ -1181,13 +1314,13 @@ hipError_t launch_sum_frames(const float *frames, uint32_t count, size_t n, uint
 // node_cache = 3: one 16-wave workgroup per CU holding the WHOLE node array in LDS (trees of at most CRT_WHOLE_TREE_NODES
 // nodes and 16 levels): no node is ever fetched from device memory.  Only instantiated for the 16-level stack (24 / 32
 // levels would not fit 160 KB).
-template <bool CW, int SD, bool SS>
+template <bool CW, int SD, bool SS, bool RING>
 static bool launch_whole_tree(const SceneView &sc, const CameraPOD &cam, const RenderArgs &a, float *out, int *ids, unsigned long long *counters,
                               uint32_t blocks, hipStream_t stream)
 {
     if constexpr (SD == 16) {
         if (a.node_cache == 3 && sc.nnodes <= CRT_WHOLE_TREE_NODES) {
-            hipLaunchKernelGGL((render_kernel<CW, 16, SS, 16, CRT_WHOLE_TREE_NODES>), dim3((blocks + 15u) / 16u), dim3(1024), 0, stream, sc, cam, a, out, ids, counters);
+            hipLaunchKernelGGL((render_kernel<CW, 16, SS, 16, CRT_WHOLE_TREE_NODES, RING>), dim3((blocks + 15u) / 16u), dim3(1024), 0, stream, sc, cam, a, out, ids, counters);
             return true;
         }
     }
@@ -1226,14 +1359,14 @@ static bool allow_dynamic_lds(Kernel kernel, size_t bytes, std::atomic<uint64_t>
 }
 
 // The kernels of a two-launch frame for a stack of SD levels and what LDS they ask for at launch (see launch_split).
-template <bool CW, int SD, bool SS>
+template <bool CW, int SD, bool SS, bool RING>
 struct SplitKernels {
     static constexpr int NA = SD == 14 ? CRT_SPLIT_A_NODES_14 : SD == 16 ? CRT_SPLIT_A_NODES_16 : CRT_SPLIT_A_NODES_24;
     static constexpr int NB = SD == 14 ? CRT_SPLIT_B_NODES_14 : SD == 16 ? CRT_SPLIT_B_NODES_16 : CRT_SPLIT_B_NODES_24;
     static constexpr size_t large_lds = dynamic_lds_bytes<SD, 16, NA, 1>(), small_lds = dynamic_lds_bytes<SD, 4, NB, 2>();
     // (a tree that fits the large copy as a whole gets the kernel without device-memory node steps; 24-level trees never do)
-    static auto large(bool whole) { return whole ? &render_kernel_dyn<CW, SD, SS, 16, NA, 1, SD != 24> : &render_kernel_dyn<CW, SD, SS, 16, NA, 1, false>; }
-    static auto small() { return &render_kernel_dyn<CW, SD, SS, 4, NB, 2, false>; }
+    static auto large(bool whole) { return whole ? &render_kernel_dyn<CW, SD, SS, 16, NA, RING, 1, SD != 24> : &render_kernel_dyn<CW, SD, SS, 16, NA, RING, 1, false>; }
+    static auto small() { return &render_kernel_dyn<CW, SD, SS, 4, NB, RING, 2, false>; }
     // allowed their dynamic LDS on `dev`: at commit (prepare_split_kernels), so that no frame -- crt_render_noalloc's included --
     // has anything left to set up; launch_split asks again, which costs one load of a bit mask
     static bool allow(int dev)
@@ -1244,7 +1377,7 @@ struct SplitKernels {
     }
 };
 
-template <bool CW, int SD, bool SS>
+template <bool CW, int SD, bool SS, bool RING>
 static bool launch_split(const SceneView &sc, const CameraPOD &cam, const RenderArgs &a, float *out, int *ids, unsigned long long *counters, uint32_t blocks,
                          hipStream_t stream, const SplitStreams *split)
 {
@@ -1256,18 +1389,20 @@ static bool launch_split(const SceneView &sc, const CameraPOD &cam, const Render
         const uint32_t cus = (blocks + 19u) / 20u; // blocks = persistent waves, 20 per CU
         if constexpr (!CW) {
             int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || !SplitKernels<CW, SD, SS>::allow(dev)) return false;
+            if (hipGetDevice(&dev) != hipSuccess || !SplitKernels<CW, SD, SS, RING>::allow(dev)) return false;
         }
         // the small workgroups start behind whatever the caller's stream holds, the caller's stream goes on behind them
         if (hipEventRecord(split->fork, stream) != hipSuccess || hipStreamWaitEvent(split->helper, split->fork, 0) != hipSuccess) return false;
+        RenderArgs b = a; // the small workgroups' waves come behind the large ones' in the frame's ring
+        b.ring_wave_base = a.ring_wave_base + 16u * cus;
         if constexpr (CW) {
             // (the instrumented variant needs more registers than 96: it keeps the forms with all of their LDS declared)
-            hipLaunchKernelGGL((render_kernel<CW, SD, SS, 16, NA>), dim3(cus), dim3(1024), 0, stream, sc, cam, a, out, ids, counters);
-            hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, NBC>), dim3(cus), dim3(256), 0, split->helper, sc, cam, a, out, ids, counters);
+            hipLaunchKernelGGL((render_kernel<CW, SD, SS, 16, NA, RING>), dim3(cus), dim3(1024), 0, stream, sc, cam, a, out, ids, counters);
+            hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, NBC, RING>), dim3(cus), dim3(256), 0, split->helper, sc, cam, b, out, ids, counters);
         } else {
-            typedef SplitKernels<CW, SD, SS> K;
+            typedef SplitKernels<CW, SD, SS, RING> K;
             hipLaunchKernelGGL(K::large(SD != 24 && sc.nnodes <= (uint32_t)NA), dim3(cus), dim3(1024), K::large_lds, stream, sc, cam, a, out, ids, counters);
-            hipLaunchKernelGGL(K::small(), dim3(cus), dim3(256), K::small_lds, split->helper, sc, cam, a, out, ids, counters);
+            hipLaunchKernelGGL(K::small(), dim3(cus), dim3(256), K::small_lds, split->helper, sc, cam, b, out, ids, counters);
         }
         if (hipEventRecord(split->join, split->helper) != hipSuccess || hipStreamWaitEvent(stream, split->join, 0) != hipSuccess) return false;
         return true;
@@ -1281,20 +1416,20 @@ static bool launch_split(const SceneView &sc, const CameraPOD &cam, const Render
 #ifndef CRT_NODE_CACHE_NODES_24
 #define CRT_NODE_CACHE_NODES_24 88  // 4 x 6.5 KB of stack + 88 x 56 B = 31.6 KB
 #endif
-template <bool CW, int SD, bool SS>
+template <bool CW, int SD, bool SS, bool RING>
 static void launch_lanes(const SceneView &sc, const CameraPOD &cam, const RenderArgs &a, float *out, int *ids, unsigned long long *counters, uint32_t blocks,
                          hipStream_t stream, const SplitStreams *split)
 {
-    if (launch_whole_tree<CW, SD, SS>(sc, cam, a, out, ids, counters, blocks, stream)) return;
-    if (a.node_cache == 4 && launch_split<CW, SD, SS>(sc, cam, a, out, ids, counters, blocks, stream, split)) return;
+    if (launch_whole_tree<CW, SD, SS, RING>(sc, cam, a, out, ids, counters, blocks, stream)) return;
+    if (a.node_cache == 4 && launch_split<CW, SD, SS, RING>(sc, cam, a, out, ids, counters, blocks, stream, split)) return;
     if constexpr (SD == 14 || SD == 16 || SD == 24) {
         constexpr int NC = SD == 14 ? CRT_NODE_CACHE_NODES_14 : SD == 16 ? CRT_NODE_CACHE_NODES : CRT_NODE_CACHE_NODES_24;
         if (a.node_cache) {
-            hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, NC>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters);
+            hipLaunchKernelGGL((render_kernel<CW, SD, SS, 4, NC, RING>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters);
             return;
         }
     }
-    hipLaunchKernelGGL((render_kernel<CW, SD, SS, 1, 0>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
+    hipLaunchKernelGGL((render_kernel<CW, SD, SS, 1, 0, RING>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
 }
 
 // At commit, with the scene's device current: everything a two-launch frame would otherwise set up on its first use.
@@ -1303,9 +1438,74 @@ hipError_t prepare_split_kernels()
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    const bool ok = SplitKernels<false, 14, false>::allow(dev) && SplitKernels<false, 14, true>::allow(dev) && SplitKernels<false, 16, false>::allow(dev) &&
-                    SplitKernels<false, 16, true>::allow(dev) && SplitKernels<false, 24, false>::allow(dev) && SplitKernels<false, 24, true>::allow(dev);
+    bool ok = true;
+#define CRT_ALLOW(SD, SS) ok = ok && SplitKernels<false, SD, SS, false>::allow(dev) && SplitKernels<false, SD, SS, true>::allow(dev)
+    CRT_ALLOW(14, false); CRT_ALLOW(14, true); CRT_ALLOW(16, false); CRT_ALLOW(16, true); CRT_ALLOW(24, false); CRT_ALLOW(24, true);
+#undef CRT_ALLOW
     return ok ? hipSuccess : hipErrorInvalidValue; // (not fatal for the caller: launch_split falls back to the one-launch form)
+}
+
+// The work queue of a frame: a.local_pixels, a.chunks and a.node_cache are final.  A block -- what a wave takes from a block counter
+// in one trip -- is 2^group_shift pixel slots = block_units work units.  Larger blocks mean fewer trips, smaller ones a more even
+// end of the frame; measured at one sample per unit (headline frame, tools/fetch_block_sweep.py, ms per frame at 128 / 256 / 512 /
+// 1024 units): whole frame 9.56 / 9.46 / 9.42 / 9.49, 1/2 of it 4.86 / 4.79 / 4.79 / 4.86, 1/4 2.46 / 2.42 / 2.42 / 2.49, 1/8
+// 1.267 / 1.254 / 1.268 / 1.34; the two-launch frame (16 + 4 split) wants at most 128: its 16-wave workgroups only leave a CU when
+// all sixteen waves have run out of work (64 / 128 / 256 / 512: whole frame 8.60 / 8.37 / 8.39 / 8.61, 1/8 1.28 / 1.27 / 1.34 / 1.49).
+// Whole pixels: a resident wave makes at least 8 trips per frame, blocks of 64..512 pixels (128 for the split).  Sample chunks: about
+// 128 units whatever the form -- a block is also what a wave keeps in its ring until all of its units are in (crt_kernels.h), and
+// at least 64 units so that one block covers a wave's request.
+static uint32_t units_per_pixel(const RenderArgs &a) { return a.chunk_mode == CM_RING ? a.spp : a.chunk_mode == CM_SLAB ? a.chunks : 1u; }
+static uint32_t chunk_group_shift(const RenderArgs &a)
+{
+    const uint32_t target = a.fetch_units ? (a.fetch_units < 64u ? 64u : a.fetch_units) : 128u, per_pixel = units_per_pixel(a);
+    uint32_t shift = 0;
+    while (shift < 6u && ((uint64_t)per_pixel << (shift + 1u)) <= target) shift++; // whole groups of pixels: at most 64 (a rank's pixel slots are a multiple of 64), at least 1
+    while (shift < 6u && ((uint64_t)per_pixel << shift) < 64u) shift++;
+    return shift;
+}
+static void plan_blocks(RenderArgs &a, uint32_t max_waves)
+{
+    a.chunk_spp = a.spp / a.chunks;
+    a.per_pixel = units_per_pixel(a);
+    a.per_pixel_magic = (uint32_t)(((1ull << 32) + a.per_pixel - 1u) / a.per_pixel);
+    if (a.chunk_mode != CM_WHOLE) a.group_shift = chunk_group_shift(a);
+    else {
+        uint32_t shift = 0;
+        if (a.fetch_units) { while ((2u << shift) <= a.fetch_units) shift++; }
+        else {
+            const uint64_t per_wave = (uint64_t)a.local_pixels / (max_waves ? max_waves : 1u);
+            const uint32_t top = a.node_cache == 4 ? 7u : 9u;
+            shift = 6;
+            while (shift < top && (16ull << shift) <= per_wave) shift++;
+        }
+        a.group_shift = shift < 6u ? 6u : shift > 16u ? 16u : shift;
+    }
+    a.block_units = a.per_pixel << a.group_shift;
+    a.nblocks = (uint32_t)((((uint64_t)a.local_pixels) + (1u << a.group_shift) - 1u) >> a.group_shift);
+    if (a.blocks_per_stripe) a.blocks_per_stripe = (a.nblocks + CRT_WORK_STRIPES - 1u) / CRT_WORK_STRIPES; // contiguous bands: ceil(blocks / stripes)
+    // the trip-counter guard of the kernel's main loop: a wave that did 64 times its share of the frame's path segments (the others
+    // may be late) at 64 passes per segment must still finish; at least 2^24 passes, at most 2^32 - 1 (20 minutes at the very least)
+    const uint64_t passes = ((uint64_t)a.local_pixels * a.per_pixel / (max_waves ? max_waves : 1u) + 1u) * 64u * (a.spp / a.per_pixel) * (a.max_depth ? a.max_depth : 1u) * 64u;
+    a.guard_passes = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(passes, 1ull << 24), 0xFFFFFFFFull);
+    if (a.ring_slots == 0) a.ring_slots = CRT_RING_SLOTS_DEFAULT;
+    a.ring_slots = a.ring_slots < 2u ? 2u : a.ring_slots > 16u ? 16u : a.ring_slots;
+    if (a.ring_batch == 0) a.ring_batch = CRT_RING_BATCH_DEFAULT;
+    a.ring_batch = a.ring_batch > a.ring_slots / 2u ? a.ring_slots / 2u : a.ring_batch; // (half of the ring stays for blocks in flight)
+}
+
+// (a workgroup form may round the persistent waves up to a multiple of 16)
+size_t render_ring_bytes(const RenderArgs &ra, uint32_t max_waves, uint32_t slots)
+{
+    if (ra.chunk_mode != CM_RING) return 0;
+    return (size_t)(max_waves + 16u) * slots * ((size_t)ra.spp << chunk_group_shift(ra)) * 3u * sizeof(float);
+}
+uint32_t render_ring_slots_that_fit(const RenderArgs &ra, uint32_t max_waves, size_t budget)
+{
+    if (ra.chunk_mode != CM_RING) return CRT_RING_SLOTS_DEFAULT;
+    uint32_t slots = ra.ring_slots ? ra.ring_slots : CRT_RING_SLOTS_DEFAULT;
+    slots = slots < 2u ? 2u : slots > 16u ? 16u : slots;
+    while (slots >= 2u && render_ring_bytes(ra, max_waves, slots) > budget) slots--;
+    return slots >= 2u ? slots : 0u;
 }
 
 hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *out, int *ids, unsigned long long *counters,
@@ -1316,39 +1516,20 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     if (local_tiles == 0) return hipSuccess;
     RenderArgs a = ra;
     a.local_pixels = local_tiles * 64u;
-    if (a.chunks == 0) a.chunks = 1;
-    a.chunk_shift = 0;
-    while ((1u << a.chunk_shift) < a.chunks) a.chunk_shift++;
-    // Work units per trip to a block counter: a power of two >= 64, so that one block always covers a wave's request.  Larger
-    // blocks mean fewer trips, smaller ones a more even end of the frame; measured at one sample per unit (headline frame,
-    // tools/fetch_block_sweep.py, ms per frame at 128 / 256 / 512 / 1024): whole frame 9.56 / 9.46 / 9.42 / 9.49, 1/2 of it
-    // 4.86 / 4.79 / 4.79 / 4.86, 1/4 2.46 / 2.42 / 2.42 / 2.49, 1/8 1.267 / 1.254 / 1.268 / 1.34.  Rule: a resident wave
-    // makes at least 8 trips per frame, blocks of 64..512 units.  The two-launch frame (16 + 4 split, below) wants at most 128: its
-    // 16-wave workgroups only leave a CU when all sixteen waves have run out of work (same sweep, 64 / 128 / 256 / 512: whole
-    // frame 8.60 / 8.37 / 8.39 / 8.61, 1/2 4.42 / 4.30 / 4.39 / 4.52, 1/4 2.31 / 2.29 / 2.31 / 2.56, 1/8 1.28 / 1.27 / 1.34 / 1.49;
-    // the 1 M-triangle grid 36.9 at 512, 36.7 at 128; cats 4K x 1024 spp 504.7 / 503.6).
-    const uint64_t units = (uint64_t)local_tiles * a.chunks; // wave-sized work units
+    if (a.chunks <= 1) { a.chunks = 1; a.chunk_mode = CM_WHOLE; }
+    else if (a.chunk_mode == CM_WHOLE) a.chunk_mode = CM_RING;
+    const uint64_t units = (uint64_t)local_tiles * units_per_pixel(a); // wave-sized work units
     const uint32_t blocks = units < max_waves ? (uint32_t)units : max_waves;
     // node_cache = 1, chosen by the frame: one that does not fill the GPU spreads better as single waves (0); one that fills it many
     // times over takes the 16 + 4 split where the tree allows it (4: the large workgroups' LDS copies and their 16 waves that
     // must all finish before the slot is free only pay on long frames); else four-wave workgroups (2)
     if (a.node_cache == 1) a.node_cache = units < max_waves ? 0u : (units >= 8ull * max_waves && split && split->helper && ra.bvh_depth <= 24 && blocks == max_waves) ? 4u : 2u;
     if (a.node_cache == 4 && !(split && split->helper && ra.bvh_depth <= 24)) a.node_cache = 2; // (asked for by name: small frames too, the tests do)
-    if (a.fetch_shift == 0) {
-        const uint64_t per_wave = (uint64_t)local_tiles * 64u * a.chunks / (max_waves ? max_waves : 1u);
-        const uint32_t top = a.node_cache == 4 ? 7u : 9u;
-        a.fetch_shift = 6;
-        while (a.fetch_shift < top && (16ull << a.fetch_shift) <= per_wave) a.fetch_shift++;
-    }
-    if (a.fetch_shift < 6) a.fetch_shift = 6;
-    if (a.fetch_shift > 16) a.fetch_shift = 16;
-    if (a.blocks_per_stripe) { // contiguous bands: ceil(blocks / stripes)
-        const uint64_t nblocks = (((uint64_t)local_tiles * 64u * a.chunks) + (1u << a.fetch_shift) - 1) >> a.fetch_shift;
-        a.blocks_per_stripe = (uint32_t)((nblocks + CRT_WORK_STRIPES - 1) / CRT_WORK_STRIPES);
-    }
+    plan_blocks(a, max_waves);
     a.tiles_x_magic = a.tiles_x > 1 ? (uint32_t)((1ull << 32) / a.tiles_x) : 0xFFFFFFFFu; // tiles_x == 1: tile / 1 = tile - (0 or 1), fixed up
     // persistent waves (blocks, above): enough to fill the device; each lane keeps drawing pixels until the counter runs out
-    if (ra.kernel == RK_POOL && a.chunks == 1) { // (the pool kernel has no sample chunks)
+#ifdef CRT_WITH_POOL_KERNEL
+    if (ra.kernel == RK_POOL && a.chunk_mode == CM_WHOLE) { // (the pool kernel has no sample chunks)
         // Experimental (CRT_KERNEL=1).  One wave per workgroup, 96 contexts, no LDS node cache: the variant that measured
         // best (8 waves sharing an LDS copy of the whole node array ran slower, 1.75 waves per SIMD
         // cannot keep the VALU busy).
@@ -1360,6 +1541,9 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
 #undef CRT_LAUNCH_POOL
         return hipGetLastError();
     }
+#else
+    if (ra.kernel == RK_POOL && a.chunk_mode == CM_WHOLE) return hipErrorNotSupported; // (crt_api.cpp only asks for it when pool_kernel_built())
+#endif
     // the LDS stack is sized by the tree: 14 levels (4 KB per wave), 16 (4.5 KB), 24 (6.5 KB: still the 20 waves per CU the registers
     // allow) or 32 (8.5 KB: 18 waves per CU)
     const bool ss = sc.sphere_slots != 0;
@@ -1367,14 +1551,25 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     // (14 levels: the kernels with 16-bit stack entries, for trees whose references fit a short -- LdsStack16)
     const bool short_refs = sc.nnodes < 32767u && sc.ntris <= 4096u;
     const int levels = (ra.bvh_depth <= 14 && short_refs && a.node_cache != 3) ? 14 : ra.bvh_depth <= 16 ? 16 : ra.bvh_depth <= 24 ? 24 : CRT_STACK_DEPTH;
-#define CRT_LAUNCH_SS(CW, SD) do { if (ss) launch_lanes<CW, SD, true>(sc, cam, a, out, ids, counters, blocks, stream, split); \
-                                   else launch_lanes<CW, SD, false>(sc, cam, a, out, ids, counters, blocks, stream, split); } while (0)
+#define CRT_LAUNCH_RING(CW, SD, SS) do { if (a.chunk_mode == CM_RING) launch_lanes<CW, SD, SS, true>(sc, cam, a, out, ids, counters, blocks, stream, split); \
+                                         else launch_lanes<CW, SD, SS, false>(sc, cam, a, out, ids, counters, blocks, stream, split); } while (0)
+#define CRT_LAUNCH_SS(CW, SD) do { if (ss) CRT_LAUNCH_RING(CW, SD, true); else CRT_LAUNCH_RING(CW, SD, false); } while (0)
 #define CRT_LAUNCH_SD(CW) do { if (levels == 14) CRT_LAUNCH_SS(CW, 14); else if (levels == 16) CRT_LAUNCH_SS(CW, 16); else if (levels == 24) CRT_LAUNCH_SS(CW, 24); \
                                else CRT_LAUNCH_SS(CW, CRT_STACK_DEPTH); } while (0)
     if (count_work) CRT_LAUNCH_SD(true); else CRT_LAUNCH_SD(false);
 #undef CRT_LAUNCH_SD
 #undef CRT_LAUNCH_SS
+#undef CRT_LAUNCH_RING
     return hipGetLastError();
+}
+
+bool pool_kernel_built()
+{
+#ifdef CRT_WITH_POOL_KERNEL
+    return true;
+#else
+    return false;
+#endif
 }
 
 hipError_t launch_untile(const float *compact_all, uint32_t width, uint32_t height, uint32_t tile_ranks, float *out, hipStream_t stream)

@@ -16,6 +16,7 @@ def _both(capi, s, cam, W, H, spp, chunks, **kw):
     got_ids = torch.full_like(want_ids, -7)
     rays = torch.zeros(1, dtype=torch.int64, device="cuda")
     stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())  # the fills above ran on the current stream: the render must come behind them
     capi.render_noalloc(s, cam, W, H, spp, got.data_ptr(), got_ids.data_ptr(), rays.data_ptr(), sample_chunks=chunks, stream=stream.cuda_stream, **kw)
     stream.synchronize()
     assert torch.equal(got, want), "image differs from crt_render's: %d floats" % int((got != want).sum())
@@ -28,9 +29,13 @@ def test_noalloc_matches_crt_render_twice_in_a_row(capi, scenes, monkeypatch, no
     import torch
     monkeypatch.setenv("CRT_NODE_CACHE", node_cache)
     s = scenes.build(scenes.cats(), 0)
-    # first call: sample chunks (the slabs of the static scratch are used), 480 x 270 x 4 chunks = 6.2 MB of slabs
+    # first call: sample chunks through slabs in the static scratch, 480 x 270 x 4 chunks = 6.2 MB
     _, cam = scenes.make_camera(480)
     _both(capi, s, cam, 480, 270, 8, 4)
+    # sample chunks whose slabs (1280 x 720 x 16 x 12 B = 177 MB) do not fit the 32 MiB: the waves' rings do, and an odd chunk count
+    _, cam3 = scenes.make_camera(1280)
+    _both(capi, s, cam3, 1280, 720, 16, 16)
+    _both(capi, s, cam, 480, 270, 9, 3, seed=3)
     # second call, smaller input, other seed and sample window, raw sums: nothing of the first frame may show through
     _, cam2 = scenes.make_camera(203)
     _both(capi, s, cam2, 203, 117, 4, 2, seed=7, sample_offset=11, ids_sample=12, flags=capi.OUT_ACCUM)
@@ -74,9 +79,16 @@ def test_noalloc_rejects_what_does_not_fit(capi, scenes):
     s = scenes.build(scenes.cat(), 0)
     _, cam = scenes.make_camera(1920)
     out = torch.empty(1080 * 1920 * 3, dtype=torch.float32, device="cuda")
-    # 1080p x 32 chunks = 796 MB of slabs: beyond the 32 MiB of the static scratch
+    # the benchmarked configuration at its full size: 1.6 GB as slabs, 31.6 MB as rings of four 128-sample blocks per wave -- accepted,
+    # and crt_render's frame (which takes the slabs) bit for bit
+    want = torch.empty_like(out)
+    s.render(cam, 1920, 1080, 64, out_rgb=want.data_ptr(), sample_chunks=64, flags=capi.OUT_DEVICE)
+    capi.render_noalloc(s, cam, 1920, 1080, 64, out.data_ptr(), sample_chunks=64)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    # 2048 samples per pixel: a ring block is at least one pixel's samples (24 KB), two of them for every persistent wave are 250 MB
     with pytest.raises(capi.CrtError) as e:
-        capi.render_noalloc(s, cam, 1920, 1080, 64, out.data_ptr(), sample_chunks=32)
+        capi.render_noalloc(s, cam, 1920, 1080, 2048, out.data_ptr(), sample_chunks=2048)
     assert e.value.code == capi.CRT_ERR_LIMIT and "32 MiB" in str(e.value)
     # the same frame with whole pixels needs no slab: accepted whatever the size
     capi.render_noalloc(s, cam, 1920, 1080, 1, out.data_ptr())

@@ -16,5 +16,5 @@ _, _, st0 = s.render(cam, W, H, spp, out_rgb=out.data_ptr(), sample_chunks=chunk
 _, _, st = s.render(cam, W, H, spp, out_rgb=out.data_ptr(), flags=capi.COUNT_WORK, sample_chunks=chunks)
 w = list(st.sched)
 print(json.dumps(dict(ms=st0.kernel_ms, rays=st.rays, nodes=st.nodes, tris=st.tri_tests, shaded=st.shaded_hits, a_runs=w[0], a_lanes=w[1], 
-                      inner_steps=w[4], inner_lanes=w[5], leaf_steps=w[6], leaf_lanes=w[7],
+                      starved_lanes=w[3], inner_steps=w[4], inner_lanes=w[5], leaf_steps=w[6], leaf_lanes=w[7],
                       waves=w[8], wave_ms_mean=w[9] / max(w[8], 1) * 1e-5, wave_ms_max=w[2] * 1e-5, count_work_ms=st.kernel_ms)))
