@@ -16,10 +16,11 @@ public:
     }
     uint32_t max_depth = 10;  // camera.h:66
     uint64_t seed = 1984;     // renderer.h:45
-    // Work units per pixel (include/crt.h: crt_render_params.sample_chunks).  UINT32_MAX (default): one sample per unit when
-    // the sample count is a power of two up to 1024 -- the fastest setting, and the frame is still the reference's
-    // sequential sample-order sum bit for bit (renderer.h:26-32) --, else whole pixels (0: one lane sums a pixel's samples
-    // in order, also bit-exact, slower).  Any other power of two dividing spp: chunk sums added in chunk order.
+    // Sample chunks per pixel (include/crt.h: crt_render_params.sample_chunks).  UINT32_MAX (default): one per sample, whatever the
+    // sample count (the reference's own 10, kernel.cu:49, included) -- the fastest setting, and the frame is still the reference's
+    // sequential sample-order sum bit for bit (renderer.h:26-32); the library keeps the scratch this needs bounded whatever the
+    // frame size (slabs while they fit a budget, else per-wave rings).  0: one lane sums a pixel's samples in order (also bit-exact,
+    // slower).  Any other divisor of spp: chunk sums added in chunk order.
     uint32_t sample_chunks = UINT32_MAX;
     // More than one GPU (new; the reference's launch_kernel_render drives one, renderer.h:64-73): the HIP devices that share
     // the frame, one logical rank each -- 8x8 tiles dealt round robin and gathered (CRT_MULTI_TILE, bitwise the one-GPU
@@ -36,8 +37,7 @@ public:
         crt_render_params p{};
         p.width = m_width; p.height = m_height; p.spp = m_samples_per_pixel; p.max_depth = max_depth; p.seed = seed;
         p.tile_rank = 0; p.tile_ranks = 1;
-        const bool pow2 = m_samples_per_pixel > 1 && (m_samples_per_pixel & (m_samples_per_pixel - 1u)) == 0 && m_samples_per_pixel <= 1024u;
-        p.sample_chunks = sample_chunks != UINT32_MAX ? sample_chunks : (pow2 ? m_samples_per_pixel : 0u);
+        p.sample_chunks = sample_chunks != UINT32_MAX ? sample_chunks : (m_samples_per_pixel > 1 ? m_samples_per_pixel : 0u);
         crt_camera cam = (*d_camera)->pod;
         cam.background[0] = (*d_camera)->background.x; // Camera::background is a public member (camera.h:23)
         cam.background[1] = (*d_camera)->background.y;

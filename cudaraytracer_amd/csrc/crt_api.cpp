@@ -877,18 +877,25 @@ static int enqueue_render(const crt_scene *s, const DeviceScene &d, const crt_ca
 }
 
 // The scratch set of `stream` on `d`, with counters, events and (sample chunks) slabs of the size this frame needs.
+// counters, events and the fork / join events of a scratch set, once
+static int init_scratch_set(DeviceScene &d, StreamScratch *x)
+{
+    if (x->d_counters) return CRT_OK;
+    HIP_TRY(hipMalloc((void **)&x->d_counters, CRT_COUNTER_BYTES));
+    HIP_TRY(hipEventCreate(&x->ev0));
+    HIP_TRY(hipEventCreate(&x->ev1));
+    HIP_TRY(hipEventCreate(&x->ev_done));
+    HIP_TRY(make_split_streams(x->split, d.noalloc_split.helper)); // (the device's one helper stream, made at commit; own events)
+    return CRT_OK;
+}
+
 static int acquire_scratch(const crt_scene *s, DeviceScene &d, hipStream_t stream, const crt_render_params *p, uint32_t chunks, StreamScratch **out)
 {
     hipEvent_t handover = nullptr;
     StreamScratch *x = d.scratch_for(stream, &handover);
     if (handover) HIP_TRY(hipStreamWaitEvent(stream, handover, 0)); // the set's previous owner finishes first
-    if (!x->d_counters) {
-        HIP_TRY(hipMalloc((void **)&x->d_counters, CRT_COUNTER_BYTES));
-        HIP_TRY(hipEventCreate(&x->ev0));
-        HIP_TRY(hipEventCreate(&x->ev1));
-        HIP_TRY(hipEventCreate(&x->ev_done));
-        HIP_TRY(make_split_streams(x->split, d.noalloc_split.helper)); // (the device's one helper stream, made at commit; own events)
-    }
+    int rc = init_scratch_set(d, x);
+    if (rc) return rc;
     x->plan = plan_chunks(s, d, p, chunks, (size_t)s->tuning.slab_budget_mb << 20, false);
     if (x->chunk_bytes < x->plan.bytes) {
         if (x->d_chunks) { HIP_TRY(hipStreamSynchronize(stream)); (void)hipFree(x->d_chunks); }

@@ -122,9 +122,9 @@ __device__ __forceinline__ void store_unit(const RenderArgs &ra, float *__restri
 {
     const bool raw = (ra.flags & RA_ACCUM) != 0 || ra.chunk_mode == CM_SLAB;
     const size_t idx = q;
-    out[3 * idx + 0] = finish_channel(col.x, (float)ra.spp, raw);
-    out[3 * idx + 1] = finish_channel(col.y, (float)ra.spp, raw);
-    out[3 * idx + 2] = finish_channel(col.z, (float)ra.spp, raw);
+    f3 o = col;
+    if (!raw) o = mk3(finish_channel(col.x, (float)ra.spp, false), finish_channel(col.y, (float)ra.spp, false), finish_channel(col.z, (float)ra.spp, false));
+    out[3 * idx + 0] = o.x; out[3 * idx + 1] = o.y; out[3 * idx + 2] = o.z; // (one twelve-byte store: every vector memory instruction costs the CU's address unit the same)
 }
 
 // pixel slot (8x8-tile order over this rank's tiles) -> column | row << 16; false: outside the image (ragged last tile column / row)

@@ -16,6 +16,7 @@ int main(int argc, char **argv)
 {
     std::vector<int> devices;
     int multi_mode = CRT_MULTI_TILE;
+    uint32_t chunks = UINT32_MAX; // Renderer's default
     bool from_mtl = false; // --mtl: every part of the model gets its .mtl material (Scene::materials_from_mtl, row N4) instead of the reference's one Lambertian
     { // options are taken out of argv; the positional arguments stay where the reference-style code below expects them
         int kept = 1;
@@ -26,6 +27,8 @@ int main(int argc, char **argv)
                 else for (int d = 0; d < atoi(v); d++) devices.push_back(d);
             } else if (!strcmp(argv[k], "--mode") && k + 1 < argc) {
                 multi_mode = !strcmp(argv[++k], "sample") ? CRT_MULTI_SAMPLE : CRT_MULTI_TILE;
+            } else if (!strcmp(argv[k], "--chunks") && k + 1 < argc) { // sample chunks per pixel (default: one per sample); 0 = whole pixels
+                chunks = (uint32_t)atoi(argv[++k]);
             } else if (!strcmp(argv[k], "--mtl")) {
                 from_mtl = true;
             } else argv[kept++] = argv[k];
@@ -66,6 +69,7 @@ int main(int argc, char **argv)
     Renderer renderer(IMAGE_WIDTH, IMAGE_HEIGHT, tx, ty, spp);
     renderer.devices = devices; // empty: the reference's single-GPU path
     renderer.multi_mode = multi_mode;
+    renderer.sample_chunks = chunks;
     const auto start = std::chrono::steady_clock::now();
     renderer.launch_kernel_render(framebuffer.data(), d_camera, d_world);
     const double timer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();

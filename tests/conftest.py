@@ -66,3 +66,13 @@ def node_cache(request, monkeypatch):
     default, 1, chooses by the frame: test-sized frames get single waves, the benchmark's the split."""
     monkeypatch.setenv("CRT_NODE_CACHE", request.param)
     return request.param
+
+
+@pytest.fixture(params=["1", "2"], ids=["slabs", "rings"])
+def chunk_mode(request, monkeypatch):
+    """Runs a GPU test with both ways of rendering sample chunks (crt_api.cpp: plan_chunks): CRT_CHUNK_MODE=1, every chunk's raw
+    sum to a scratch of pixels x chunks and a second kernel that adds a pixel's chunk sums (what the default takes while the
+    scratch fits its budget); CRT_CHUNK_MODE=2, one sample per work unit and the wave that rendered a block of pixels adds
+    it up itself through its ring (what frames too large for slabs and crt_render_noalloc take).  Same frame bit for bit."""
+    monkeypatch.setenv("CRT_CHUNK_MODE", request.param)
+    return request.param

@@ -30,7 +30,7 @@ def test_surface_compiles_and_fails_loudly_without_gpu(capi, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("spp", [3, 4])   # 3: whole pixels; 4 (a power of two): Renderer's default of one sample per work unit -- both bit-exact
+@pytest.mark.parametrize("spp", [1, 3, 4, 10])   # Renderer's default is one sample per work unit for any count (10: the reference's own, kernel.cu:49)
 def test_reference_style_driver_matches_oracle(oracle, scenes, tmp_path, spp):
     assert os.path.exists(DEMO), "examples/crt_demo not built (python __graft_entry__.py)"
     W, H = 200, 120
@@ -61,3 +61,14 @@ def test_reference_style_driver_sphere_scene(tmp_path):
     assert img.shape == (180, 320, 3)
     sky = img[:20].reshape(-1, 3).mean(axis=0)
     assert sky[2] > sky[0] > 150 and img[100:].std() > 20      # blue-ish sky on top, structure below
+
+
+@pytest.mark.gpu
+def test_reference_style_driver_large_frame_many_samples(tmp_path):
+    """Renderer's default (one sample per work unit) at a size whose chunk slabs would be 25 GB (3840 x 2160 x 256 x 12 B): the
+    library must keep its scratch bounded by itself (per-wave rings beyond the slab budget) instead of failing or allocating it."""
+    r = subprocess.run([DEMO, os.path.join(helpers.REPO, "models", "cat.obj"), "3840", "2160", "256"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    from tests.test_output import decode_png
+    img = decode_png(str(tmp_path / "output.png"))
+    assert img.shape == (2160, 3840, 3) and img.std() > 10

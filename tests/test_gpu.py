@@ -252,7 +252,7 @@ def test_context_pool_kernel_matches_default_kernel(monkeypatch, scenes, gpu_sce
         assert np.array_equal(rgb0, rgb1) and np.array_equal(ids0, ids1) and st0.rays == st1.rays
 
 
-def test_sample_chunks_match_chunked_sum_of_oracle(oracle, scenes, gpu_scenes, node_cache):
+def test_sample_chunks_match_chunked_sum_of_oracle(oracle, scenes, gpu_scenes, node_cache, chunk_mode):
     """sample_chunks = n: the work unit is (pixel, chunk of spp/n samples); every sample is the same, each chunk is
     summed in sample order and the chunk sums are added in chunk order.  The oracle's raw sums per chunk, combined the
     same way in float32, must reproduce the image bit for bit; against the unchunked image the tolerance is float
@@ -282,12 +282,14 @@ def test_sample_chunks_match_chunked_sum_of_oracle(oracle, scenes, gpu_scenes, n
     assert np.array_equal(full.reshape(expect.shape), expect)
 
 
-@pytest.mark.parametrize("name,width,height,spp", [("cats", 97, 45, 8), ("cat_checker", 64, 36, 4), ("cats", 43, 19, 64)])
-def test_one_sample_per_chunk_is_the_sequential_sum(oracle, scenes, gpu_scenes, name, width, height, spp):
-    """sample_chunks = spp: every work unit is one sample, the finalize pass adds a pixel's single-sample slabs in sample
-    order starting from 0 -- the float operations of the reference's loop (renderer.h:26-32).  So the frame must be the
-    oracle's image (the sequential sum) bit for bit, ids and ray count included: the parallel decomposition bench.py times
-    costs no exactness.  Ragged frame sizes, raw sums and compact tile lists as well."""
+@pytest.mark.parametrize("name,width,height,spp", [("cats", 97, 45, 8), ("cat_checker", 64, 36, 4), ("cats", 43, 19, 64),
+                                                   ("cats", 97, 45, 3), ("cat", 120, 67, 10), ("cats", 75, 41, 12), ("cat", 33, 17, 100)])
+def test_one_sample_per_chunk_is_the_sequential_sum(oracle, scenes, gpu_scenes, chunk_mode, name, width, height, spp):
+    """sample_chunks = spp: every work unit is one sample, and a pixel's single samples are added in sample order starting
+    from 0 -- the float operations of the reference's loop (renderer.h:26-32) -- by the chunk-sum pass (slabs) or by the wave
+    that rendered them (rings).  So the frame must be the oracle's image (the sequential sum) bit for bit, ids and ray count
+    included: the parallel decomposition bench.py times costs no exactness.  Any sample count (3, 10 -- the reference's own
+    literal, kernel.cu:49 --, 12, 100: no power of two is needed), ragged frame sizes, raw sums and compact tile lists as well."""
     from cudaraytracer_amd import capi
     desc, s = gpu_scenes(name)
     params, cam = scenes.make_camera(width)
@@ -376,7 +378,7 @@ def test_randomised_configurations_against_oracle(oracle, scenes, gpu_scenes, ca
         parts = [s.render(cam, width, height, spp, tile_rank=r, tile_ranks=ranks, flags=capi.OUT_COMPACT, **kw)[0] for r in range(ranks)]
         assert np.array_equal(helpers.untile_numpy(np.concatenate(parts), width, height, ranks), fb), (trial, "tiles", ranks)
         # sample chunks
-        chunks = [c for c in (2, 4, 8) if spp % c == 0]
+        chunks = [c for c in (2, 3, 4, 5, 6, 7, 8, 9, 11) if spp % c == 0 and c <= spp]
         if chunks:
             n = int(rng.choice(chunks))
             total = None
@@ -435,8 +437,8 @@ def test_pipelined_tile_gather_over_rccl_single_rank(scenes, gpu_scenes, capi):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("spp,n", [(64, 64), (128, 128), (256, 32)])
-def test_many_sample_chunks(oracle, scenes, gpu_scenes, capi, spp, n):
+@pytest.mark.parametrize("spp,n", [(64, 64), (128, 128), (256, 32), (30, 6), (21, 3), (130, 130)])
+def test_many_sample_chunks(oracle, scenes, gpu_scenes, capi, chunk_mode, spp, n):
     """Chunk counts at and above the 64 units of a work block (a pixel's chunks then span several blocks and several waves),
     on a ragged frame; raw sums against the oracle's per-chunk sums added in chunk order, ids and ray count exact."""
     desc, s = gpu_scenes("cats")
