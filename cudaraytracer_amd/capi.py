@@ -58,7 +58,8 @@ class SceneInfo(C.Structure):  # crt_scene_info
     _fields_ = [("num_triangles", C.c_uint32), ("num_spheres", C.c_uint32), ("num_materials", C.c_uint32), ("num_textures", C.c_uint32),
                 ("num_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("max_leaf_size", C.c_uint32), ("device", C.c_uint32),
                 ("node_bytes", C.c_uint64), ("triangle_bytes", C.c_uint64), ("sphere_bytes", C.c_uint64),
-                ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3), ("builder", C.c_uint32), ("build_ms", C.c_float)]
+                ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3), ("builder", C.c_uint32), ("build_ms", C.c_float),
+                ("node_width", C.c_uint32), ("binary_depth", C.c_uint32)]
 
 
 # every symbol include/crt.h declares (tests check that the library exports exactly these)

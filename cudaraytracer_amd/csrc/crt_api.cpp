@@ -249,6 +249,7 @@ struct Tuning {
     int slab_budget_mb = 2048; // CRT_SLAB_BUDGET_MB: the largest chunk scratch a frame may ask for before it takes the ring instead
     int ring_batch = 0;        // CRT_RING_BATCH: sample chunks, complete blocks a wave lets collect before one pass adds them up (0 = default)
     int ring_slots = 0;        // CRT_RING_SLOTS: sample chunks, blocks a wave may have in flight in its ring (2..16; 0 = default, crt_kernels.h)
+    int bvh_wide = 0;          // CRT_BVH_WIDE: 1 = four-child nodes (crt_bvh.h: widen_bvh); read at commit only.  Off by default: measured slower
     void from_env()
     {
         kernel = get_env_int("CRT_KERNEL", 0) == 1 ? 1 : 0;
@@ -263,6 +264,7 @@ struct Tuning {
         ring_batch = std::min(std::max(get_env_int("CRT_RING_BATCH", 0), 0), 8);
         chunk_mode = std::min(std::max(get_env_int("CRT_CHUNK_MODE", 0), 0), 2);
         slab_budget_mb = std::max(get_env_int("CRT_SLAB_BUDGET_MB", 2048), 0);
+        bvh_wide = get_env_int("CRT_BVH_WIDE", 0) == 1 ? 1 : 0;
     }
 };
 
@@ -376,7 +378,7 @@ struct crt_scene {
     FlatBvh bvh;
     std::vector<Shade> shades; // materials joined with their textures (device record)
     std::vector<q4> normals;   // per triangle slot: unit normal + primitive id (crt_traverse.h: triangle_normal)
-    uint32_t builder = 0; float build_ms = 0.0f;
+    uint32_t builder = 0, binary_depth = 0; float build_ms = 0.0f;
     std::vector<Sphere> flat_spheres; // the spheres that are tested before the walk (the others are slots of the tree)
     bool sphere_slots = false;        // some spheres went into the tree
     Tuning tuning;
@@ -600,6 +602,16 @@ static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
         s->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     }
     if (s->bvh.depth > CRT_STACK_DEPTH) return fail(CRT_ERR_LIMIT, "crt_scene_commit: BVH deeper than the traversal stack");
+    // Four children per node (CRT_BVH_WIDE=1): half the levels, half the node fetches per ray, and 2.3 times the instructions per
+    // fetch -- the kernel is bound by instruction issue, not by the latency of dependent fetches, so the two-child format stays
+    // the default (DESIGN.md section 4 has the measurement).  The kernels for this format have the 16-level stack
+    // (crt_kernels.hip: launch_wide); a tree that stays deeper than that keeps two children.
+    s->binary_depth = s->bvh.depth;
+    if (s->tuning.bvh_wide == 1) {
+        FlatBvh wide = s->bvh;
+        widen_bvh(wide);
+        if (wide.wide && wide.depth <= 16) s->bvh = std::move(wide);
+    }
 
     s->shades.assign(s->mats.size(), Shade{});
     for (size_t k = 0; k < s->mats.size(); k++) {
@@ -668,7 +680,7 @@ static int upload_replica(crt_scene *s, DeviceScene &d, int device)
     SceneView &v = d.view;
     v.nodes = (const q4 *)d.d_nodes; v.tris = (const q4 *)d.d_tris; v.spheres = (const Sphere *)d.d_spheres;
     v.shades = (const Shade *)d.d_shades; v.normals = (const q4 *)d.d_normals;
-    v.root_ref = s->bvh.root_ref; v.nnodes = (uint32_t)(s->bvh.nodes.size() / 4); v.ntris = (uint32_t)(s->bvh.tris.size() / 3);
+    v.root_ref = s->bvh.root_ref; v.wide = s->bvh.wide ? 1u : 0u; v.nnodes = (uint32_t)(s->bvh.nodes.size() / (s->bvh.wide ? 8 : 4)); v.ntris = (uint32_t)(s->bvh.tris.size() / 3);
     v.nspheres = (uint32_t)s->flat_spheres.size(); v.sphere_slots = s->sphere_slots ? 1u : 0u;
     v.root_min = s->bvh.root_box.mn; v.root_max = s->bvh.root_box.mx;
     return CRT_OK;
@@ -701,12 +713,12 @@ extern "C" int crt_scene_get_info(const crt_scene *s, crt_scene_info *info)
     memset(info, 0, sizeof *info);
     info->num_triangles = (uint32_t)s->tris.size(); info->num_spheres = (uint32_t)s->spheres.size();
     info->num_materials = (uint32_t)s->mats.size(); info->num_textures = (uint32_t)s->texs.size();
-    info->num_nodes = (uint32_t)(s->bvh.nodes.size() / 4); info->bvh_depth = s->bvh.depth; info->max_leaf_size = s->bvh.max_leaf;
+    info->num_nodes = (uint32_t)(s->bvh.nodes.size() / (s->bvh.wide ? 8 : 4)); info->bvh_depth = s->bvh.depth; info->max_leaf_size = s->bvh.max_leaf;
     info->device = s->committed ? (uint32_t)s->device : UINT32_MAX;
     info->node_bytes = s->bvh.nodes.size() * sizeof(q4); info->triangle_bytes = s->bvh.tris.size() * sizeof(q4);
     info->sphere_bytes = s->flat_spheres.size() * sizeof(Sphere);
     info->bounds_min[0] = s->bvh.root_box.mn.x; info->bounds_min[1] = s->bvh.root_box.mn.y; info->bounds_min[2] = s->bvh.root_box.mn.z;
-    info->builder = s->builder; info->build_ms = s->build_ms;
+    info->builder = s->builder; info->build_ms = s->build_ms; info->node_width = s->bvh.wide ? 4u : 2u; info->binary_depth = s->binary_depth;
     info->bounds_max[0] = s->bvh.root_box.mx.x; info->bounds_max[1] = s->bvh.root_box.mx.y; info->bounds_max[2] = s->bvh.root_box.mx.z;
     return CRT_OK;
 }

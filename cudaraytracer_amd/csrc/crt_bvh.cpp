@@ -341,6 +341,79 @@ void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t
     renumber_breadth_first(out.nodes, out.root_ref);
 }
 
+// Two-child tree -> four-child tree (crt_traverse.h: trav_inner4_from).  A wide node starts as a two-child node's pair of
+// children; the inner child with the largest box is replaced by its own two children until there are four or only leaves are
+// left (the usual collapse: every root-to-leaf path loses about half of its levels).  Nodes are emitted breadth first, so "the
+// first N nodes" is still the top of the tree; a reference to a wide node carries the mask of the children it has.
+void widen_bvh(FlatBvh &bvh)
+{
+    if (bvh.wide || bvh.root_ref < 0 || bvh.root_ref == CRT_BVH_NONE) return; // (no node at all: a single leaf, or nothing)
+    struct Child { Box box; int ref; };
+    auto child_of = [&](int node, int k) {
+        const q4 *q = &bvh.nodes[4 * (size_t)node];
+        Child c;
+        c.box.mn = mk3(q[2 * k].x, q[2 * k].y, q[2 * k].z); c.box.mx = mk3(q[2 * k + 1].x, q[2 * k + 1].y, q[2 * k + 1].z);
+        std::memcpy(&c.ref, &q[k].w, 4);
+        return c;
+    };
+    auto area = [](const Box &b) {
+        const double dx = (double)b.mx.x - b.mn.x, dy = (double)b.mx.y - b.mn.y, dz = (double)b.mx.z - b.mn.z;
+        return dx * dy + dy * dz + dz * dx;
+    };
+    struct Wide { Child c[4]; int n; };
+    std::vector<Wide> wide;            // breadth first
+    std::vector<int> source;           // two-child node a wide node was grown from
+    std::vector<int> wide_of(bvh.nodes.size() / 4, -1);
+    source.push_back(bvh.root_ref); wide_of[(size_t)bvh.root_ref] = 0;
+    uint32_t depth = 0;
+    for (size_t head = 0; head < source.size(); head++) {
+        Wide w;
+        w.c[0] = child_of(source[head], 0); w.c[1] = child_of(source[head], 1); w.n = 2;
+        while (w.n < 4) {
+            int best = -1;
+            double best_area = -1.0;
+            for (int k = 0; k < w.n; k++)
+                if (w.c[k].ref >= 0 && area(w.c[k].box) > best_area) { best_area = area(w.c[k].box); best = k; }
+            if (best < 0) break;
+            const int node = w.c[best].ref;
+            w.c[best] = child_of(node, 0);
+            w.c[w.n++] = child_of(node, 1);
+        }
+        wide.push_back(w);
+        for (int k = 0; k < w.n; k++)
+            if (w.c[k].ref >= 0) { wide_of[(size_t)w.c[k].ref] = (int)source.size(); source.push_back(w.c[k].ref); }
+    }
+    if (wide.size() > (size_t)CRT_WIDE_INDEX) return; // (more nodes than a reference can name: stays two-child)
+    std::vector<uint32_t> level(wide.size(), 1); // parents come before their children
+    std::vector<q4> out(8 * wide.size());
+    for (size_t i = 0; i < wide.size(); i++) {
+        const Wide &w = wide[i];
+        depth = std::max(depth, level[i]);
+        float f[7][4];
+        for (int k = 0; k < 4; k++) {
+            const bool have = k < w.n;
+            const Box b = have ? w.c[k].box : Box{ mk3(0, 0, 0), mk3(0, 0, 0) }; // (a child that does not exist is never named by a mask)
+            f[0][k] = b.mn.x; f[1][k] = b.mn.y; f[2][k] = b.mn.z; f[3][k] = b.mx.x; f[4][k] = b.mx.y; f[5][k] = b.mx.z;
+            int ref = CRT_BVH_NONE;
+            if (have) {
+                ref = w.c[k].ref;
+                if (ref >= 0) {
+                    const int child = wide_of[(size_t)ref];
+                    level[(size_t)child] = level[i] + 1;
+                    ref = (int)(((uint32_t)((1 << wide[(size_t)child].n) - 1) << CRT_WIDE_SHIFT) | (uint32_t)child);
+                }
+            }
+            std::memcpy(&f[6][k], &ref, 4);
+        }
+        for (int r = 0; r < 7; r++) { q4 &q = out[8 * i + (size_t)r]; q.x = f[r][0]; q.y = f[r][1]; q.z = f[r][2]; q.w = f[r][3]; }
+        out[8 * i + 7] = q4{ 0, 0, 0, 0 };
+    }
+    bvh.nodes.swap(out);
+    bvh.root_ref = (int)(((uint32_t)((1 << wide[0].n) - 1) << CRT_WIDE_SHIFT) | 0u);
+    bvh.depth = depth;
+    bvh.wide = true;
+}
+
 float reciprocal_if_exact(float s)
 {
     if (!(s >= 0x1p-20f && s <= 0x1p+20f)) return 0.0f;

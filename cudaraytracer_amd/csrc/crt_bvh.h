@@ -30,7 +30,8 @@ Box reference_sphere_box(const HostSphere &s);
 void reference_ranks(const std::vector<Box> &boxes, std::vector<uint32_t> &rank, Box &scene_box);
 
 struct FlatBvh {
-    std::vector<q4> nodes;   // 4 per node
+    std::vector<q4> nodes;   // 4 per two-child node, 8 per four-child node
+    bool wide = false;       // four-child nodes (widen_bvh)
     std::vector<q4> tris;    // 3 per slot
     int root_ref = CRT_BVH_NONE;
     Box root_box{};
@@ -46,6 +47,9 @@ struct BvhSphere { HostSphere s; uint32_t id; uint32_t rank; };
 // rank[i] is the rank of triangle i.  max_leaf in 1..8.
 void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t> &rank, const std::vector<BvhSphere> &spheres, uint32_t max_leaf,
                FlatBvh &out);
+
+// Two-child tree -> four-child tree of 128-byte nodes (crt_traverse.h), breadth first; depth becomes the wide tree's.
+void widen_bvh(FlatBvh &bvh);
 
 // Breadth-first renumbering of a flattened tree (drops unreachable records): what "the first N nodes" means to the kernels.
 void renumber_breadth_first(std::vector<q4> &nodes, int &root_ref);

@@ -242,6 +242,24 @@ struct CachedNodes {
 };
 
 
+// Four-child nodes (crt_traverse.h): 112 bytes of a 128-byte device record, the first `ncached` of them from the LDS copy.
+#define CRT_LDS_WIDE_WORDS 28u
+struct CachedNodes4 {
+    const q4 *global;
+    lds_q4_ptr lds;
+    uint32_t ncached;
+    __device__ __forceinline__ void fetch(uint32_t idx, q4 &mnx, q4 &mny, q4 &mnz, q4 &mxx, q4 &mxy, q4 &mxz, q4 &ref) const
+    {
+        if (idx < ncached) {
+            lds_q4_ptr n = lds + 7u * idx;
+            mnx = to_q4(n[0]); mny = to_q4(n[1]); mnz = to_q4(n[2]); mxx = to_q4(n[3]); mxy = to_q4(n[4]); mxz = to_q4(n[5]); ref = to_q4(n[6]);
+        } else {
+            const q4 *n = global + 8u * idx;
+            mnx = n[0]; mny = n[1]; mnz = n[2]; mxx = n[3]; mxy = n[4]; mxz = n[5]; ref = n[6];
+        }
+    }
+};
+
 struct LdsNodes { // the LDS copy only (the caller has checked cur < ncached)
     lds_q4_ptr lds;
     __device__ __forceinline__ void fetch(int cur, q4 &n0, q4 &n1, q4 &n2, q4 &n3) const
@@ -379,7 +397,7 @@ static_assert(CRT_WORK_STRIPES == 64u, "the order in which a wave visits the blo
 #endif
 extern __shared__ int lds_dynamic[]; // render_kernel_dyn's stacks (DYNAMIC = 1) or node copy + stacks (DYNAMIC = 2), see there
 // WHOLE: the launcher has checked that the whole node array is in the LDS copy (sc.nnodes <= NC): no device-memory node step exists
-template <bool COUNT_WORK, int SD, bool SS, int W, int NC, bool RING, int DYNAMIC = 0, bool WHOLE = false>
+template <bool COUNT_WORK, int SD, bool SS, int W, int NC, bool RING, int DYNAMIC = 0, bool WHOLE = false, bool WIDE4 = false>
 __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD &cam, const RenderArgs &ra, float *__restrict__ out,
                                             int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
@@ -391,7 +409,7 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
     float *lds_nodes;
     if constexpr (DYNAMIC == 2) lds_nodes = reinterpret_cast<float *>(lds_dynamic);
     else {
-        __shared__ float lds_nodes_static[NC > 0 ? CRT_LDS_NODE_WORDS * NC : 1];
+        __shared__ __align__(16) float lds_nodes_static[NC > 0 ? (WIDE4 ? CRT_LDS_WIDE_WORDS : CRT_LDS_NODE_WORDS) * NC : 1];
         lds_nodes = lds_nodes_static;
     }
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -400,20 +418,29 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
     constexpr int NONE = stack_none<stack_t>::value;
     constexpr int STACK_INTS = (SD + 2) * 64 * (int)sizeof(typename stack_t::entry) / 4; // per wave
     int *lds_stack;
-    if constexpr (DYNAMIC != 0) lds_stack = lds_dynamic + (DYNAMIC == 2 ? CRT_LDS_NODE_WORDS * NC : 0) + wave * STACK_INTS;
+    if constexpr (DYNAMIC != 0) lds_stack = lds_dynamic + (DYNAMIC == 2 ? (WIDE4 ? CRT_LDS_WIDE_WORDS : CRT_LDS_NODE_WORDS) * NC : 0) + wave * STACK_INTS;
     else {
         __shared__ int lds_stack_all[W][STACK_INTS];
         lds_stack = lds_stack_all[wave];
     }
     CachedNodes node_src;
     node_src.global = sc.nodes; node_src.lds = (lds_q4_ptr)lds_nodes; node_src.ncached = NC > 0 ? min((int)sc.nnodes, NC) : 0;
+    CachedNodes4 node_src4;
+    node_src4.global = sc.nodes; node_src4.lds = (lds_q4_ptr)lds_nodes; node_src4.ncached = (uint32_t)node_src.ncached;
     if (NC > 0) {
-        // word j of the 56-byte LDS record <- word of the 64-byte device record: the four rows' xyz, then the two references
         const float *g = reinterpret_cast<const float *>(sc.nodes);
-        for (uint32_t k = threadIdx.x; k < CRT_LDS_NODE_WORDS * (uint32_t)node_src.ncached; k += 64u * W) {
-            const uint32_t node = k / CRT_LDS_NODE_WORDS, j = k - node * CRT_LDS_NODE_WORDS;
-            const uint32_t src = j < 12u ? (j / 3u) * 4u + j % 3u : (j == 12u ? 3u : 7u);
-            lds_nodes[k] = g[16u * node + src];
+        if constexpr (WIDE4) { // the first 28 words of the 32-word device record
+            for (uint32_t k = threadIdx.x; k < CRT_LDS_WIDE_WORDS * (uint32_t)node_src.ncached; k += 64u * W) {
+                const uint32_t node = k / CRT_LDS_WIDE_WORDS, j = k - node * CRT_LDS_WIDE_WORDS;
+                lds_nodes[k] = g[32u * node + j];
+            }
+        } else {
+            // word j of the 56-byte LDS record <- word of the 64-byte device record: the four rows' xyz, then the two references
+            for (uint32_t k = threadIdx.x; k < CRT_LDS_NODE_WORDS * (uint32_t)node_src.ncached; k += 64u * W) {
+                const uint32_t node = k / CRT_LDS_NODE_WORDS, j = k - node * CRT_LDS_NODE_WORDS;
+                const uint32_t src = j < 12u ? (j / 3u) * 4u + j % 3u : (j == 12u ? 3u : 7u);
+                lds_nodes[k] = g[16u * node + src];
+            }
         }
         __syncthreads(); // the only workgroup barrier: from here on the waves do not meet again
     }
@@ -519,7 +546,7 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
             if (active && phase == P_HIT) {
                 float t = 0.0f;
                 int mat = 0;
-                const int code = resolve_hit_in_place(sck, p.o, p.d, tmin, FLT_MAX, hit, t, mat, stack, cnt, tv); // (hit and tv are dead here)
+                const int code = resolve_hit_in_place<stack_t, decltype(cnt), WIDE4 ? 1 : 0>(sck, p.o, p.d, tmin, FLT_MAX, hit, t, mat, stack, cnt, tv); // (hit and tv are dead here)
                 if (code < 0) { // camera.h:68-71
                     p.color = mk3(fma1(p.attenuation.x, cam.background.x, p.color.x), fma1(p.attenuation.y, cam.background.y, p.color.y),
                                   fma1(p.attenuation.z, cam.background.z, p.color.z));
@@ -725,6 +752,26 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
                 // occupies the CU's one address unit for 16 cycles whatever the number of active lanes, so a step that
                 // fetches from device memory at all may as well do so for every lane at a node; when at least 3/4 of those
                 // lanes are at cached nodes the step is LDS-only instead and the others wait.
+                if constexpr (WIDE4) {
+                    // four-child nodes: one kind of step, every lane at a node takes part and reads its node from the LDS copy or from
+                    // device memory (the trees that get this format are far larger than any copy: most reads are device reads anyway)
+                    if (n_inner >= n_leaf) {
+                        if constexpr (COUNT_WORK) { if (lane == 0) { wc[4]++; wc[5] += n_inner; } }
+                        if (inner) trav_inner4_from(node_src4, tv, stack, cnt);
+#pragma unroll
+                        for (int k = 1; k < CRT_NODE_STEPS_PER_VOTE; k++) {
+                            const bool again = inner && is_inner<NONE>(tv.cur);
+                            if constexpr (COUNT_WORK) { const int na = popc64(__ballot(again)); if (lane == 0) { wc[4]++; wc[5] += na; } }
+                            if (again) trav_inner4_from(node_src4, tv, stack, cnt);
+                        }
+                        CRT_LAP(clk, 7);
+                    } else {
+                        if constexpr (COUNT_WORK) { if (lane == 0) { wc[6]++; wc[7] += n_leaf; } }
+                        if (leaf) trav_leaf<MODE_CLOSEST>(sc, p.o, p.d, tmin, hit, 0, 0.0f, tv, stack, cnt);
+                        CRT_LAP(clk, 8);
+                    }
+                    continue;
+                }
                 bool in_lds = false;
                 int n_lds = 0;
                 if constexpr (WHOLE) { in_lds = inner; n_lds = n_inner; }
@@ -804,11 +851,11 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
     }
 }
 
-template <bool COUNT_WORK, int SD, bool SS, int W, int NC, bool RING>
+template <bool COUNT_WORK, int SD, bool SS, int W, int NC, bool RING, bool WIDE4 = false>
 __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out,
                                                                        int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
-    render_body<COUNT_WORK, SD, SS, W, NC, RING>(sc, cam, ra, out, ids, counters);
+    render_body<COUNT_WORK, SD, SS, W, NC, RING, 0, false, WIDE4>(sc, cam, ra, out, ids, counters);
 }
 
 // The 16-wave workgroup of a two-launch frame (launch_split).  With all of its LDS declared (one workgroup per CU) the compiler
@@ -820,15 +867,16 @@ __global__ __launch_bounds__(64 * W) CRT_OCCUPANCY_ATTR void render_kernel(Scene
 // the same 32 registers per SIMD lane free as five 96-register waves do.  The small workgroup of the pair has the same problem
 // from 32 KB of LDS on (four waves per SIMD by LDS -> 128 registers): with node copy AND stacks dynamic (DYNAMIC = 2) it can use
 // whatever the large one leaves.
-template <int SD, int W, int NC, int DYNAMIC> constexpr size_t dynamic_lds_bytes()
+template <int SD, int W, int NC, int DYNAMIC, bool WIDE4 = false> constexpr size_t dynamic_lds_bytes()
 {
-    return (size_t)W * (SD + 2) * 64 * (SD == 14 ? sizeof(short) : sizeof(int)) + (DYNAMIC == 2 ? (size_t)CRT_LDS_NODE_BYTES * NC : 0); // (14 levels: 16-bit entries)
+    return (size_t)W * (SD + 2) * 64 * (SD == 14 ? sizeof(short) : sizeof(int)) + // (14 levels: 16-bit entries)
+           (DYNAMIC == 2 ? (size_t)(WIDE4 ? 4u * CRT_LDS_WIDE_WORDS : CRT_LDS_NODE_BYTES) * NC : 0);
 }
-template <bool COUNT_WORK, int SD, bool SS, int W, int NC, bool RING, int DYNAMIC, bool WHOLE = false>
+template <bool COUNT_WORK, int SD, bool SS, int W, int NC, bool RING, int DYNAMIC, bool WHOLE = false, bool WIDE4 = false>
 __global__ __launch_bounds__(64 * W) __attribute__((amdgpu_waves_per_eu(CRT_WAVES_PER_EU, CRT_WAVES_PER_EU)))
 void render_kernel_dyn(SceneView sc, CameraPOD cam, RenderArgs ra, float *__restrict__ out, int *__restrict__ ids, unsigned long long *__restrict__ counters)
 {
-    render_body<COUNT_WORK, SD, SS, W, NC, RING, DYNAMIC, WHOLE>(sc, cam, ra, out, ids, counters);
+    render_body<COUNT_WORK, SD, SS, W, NC, RING, DYNAMIC, WHOLE, WIDE4>(sc, cam, ra, out, ids, counters);
 }
 
 #ifdef CRT_WITH_POOL_KERNEL // experimental, measured and rejected: built with EXTRA_DEVFLAGS=-DCRT_WITH_POOL_KERNEL only
@@ -1432,6 +1480,52 @@ static void launch_lanes(const SceneView &sc, const CameraPOD &cam, const Render
     hipLaunchKernelGGL((render_kernel<CW, SD, SS, 1, 0, RING>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
 }
 
+// Four-child nodes (SceneView.wide; crt_api.cpp widens the trees that are deep and large): the same forms -- 16 + 4 split, four-wave
+// workgroups, single waves -- for the 16-level stack with 32-bit entries (an entry carries a four-bit child mask above the index,
+// and a wide tree is at most half as deep as the two-child tree it was made from).
+#define CRT_WIDE_A_NODES 584 // 16 x 4.5 KB of stack + 584 x 112 B = 135.9 KB
+#define CRT_WIDE_B_NODES 38  //  4 x 4.5 KB of stack +  38 x 112 B =  22.2 KB
+#define CRT_WIDE_C_NODES 118 //  4 x 4.5 KB of stack + 118 x 112 B =  31.2 KB (below 32 KB: see above)
+template <bool CW, bool SS, bool RING>
+struct WideKernels {
+    static constexpr size_t large_lds = dynamic_lds_bytes<16, 16, CRT_WIDE_A_NODES, 1, true>(), small_lds = dynamic_lds_bytes<16, 4, CRT_WIDE_B_NODES, 2, true>();
+    static auto large() { return &render_kernel_dyn<CW, 16, SS, 16, CRT_WIDE_A_NODES, RING, 1, false, true>; }
+    static auto small() { return &render_kernel_dyn<CW, 16, SS, 4, CRT_WIDE_B_NODES, RING, 2, false, true>; }
+    static bool allow(int dev)
+    {
+        static std::atomic<uint64_t> done[2];
+        return allow_dynamic_lds(large(), large_lds, done[0], dev) && allow_dynamic_lds(small(), small_lds, done[1], dev);
+    }
+};
+template <bool CW, bool SS, bool RING>
+static void launch_wide(const SceneView &sc, const CameraPOD &cam, const RenderArgs &a, float *out, int *ids, unsigned long long *counters, uint32_t blocks,
+                        hipStream_t stream, const SplitStreams *split)
+{
+    int dev = 0;
+    if (a.node_cache == 4 && split && split->helper && hipGetDevice(&dev) == hipSuccess && (CW || WideKernels<CW, SS, RING>::allow(dev)) &&
+        hipEventRecord(split->fork, stream) == hipSuccess && hipStreamWaitEvent(split->helper, split->fork, 0) == hipSuccess) {
+        const uint32_t cus = (blocks + 19u) / 20u;
+        RenderArgs b = a;
+        b.ring_wave_base = a.ring_wave_base + 16u * cus;
+        if constexpr (CW) {
+            hipLaunchKernelGGL((render_kernel<CW, 16, SS, 16, CRT_WIDE_A_NODES, RING, true>), dim3(cus), dim3(1024), 0, stream, sc, cam, a, out, ids, counters);
+            hipLaunchKernelGGL((render_kernel<CW, 16, SS, 4, CRT_WIDE_B_NODES, RING, true>), dim3(cus), dim3(256), 0, split->helper, sc, cam, b, out, ids, counters);
+        } else {
+            typedef WideKernels<CW, SS, RING> K;
+            hipLaunchKernelGGL(K::large(), dim3(cus), dim3(1024), K::large_lds, stream, sc, cam, a, out, ids, counters);
+            hipLaunchKernelGGL(K::small(), dim3(cus), dim3(256), K::small_lds, split->helper, sc, cam, b, out, ids, counters);
+        }
+        (void)hipEventRecord(split->join, split->helper);
+        (void)hipStreamWaitEvent(stream, split->join, 0);
+        return;
+    }
+    if (a.node_cache) {
+        hipLaunchKernelGGL((render_kernel<CW, 16, SS, 4, CRT_WIDE_C_NODES, RING, true>), dim3((blocks + 3u) / 4u), dim3(256), 0, stream, sc, cam, a, out, ids, counters);
+        return;
+    }
+    hipLaunchKernelGGL((render_kernel<CW, 16, SS, 1, 0, RING, true>), dim3(blocks), dim3(64), 0, stream, sc, cam, a, out, ids, counters);
+}
+
 // At commit, with the scene's device current: everything a two-launch frame would otherwise set up on its first use.
 hipError_t prepare_split_kernels()
 {
@@ -1442,6 +1536,8 @@ hipError_t prepare_split_kernels()
 #define CRT_ALLOW(SD, SS) ok = ok && SplitKernels<false, SD, SS, false>::allow(dev) && SplitKernels<false, SD, SS, true>::allow(dev)
     CRT_ALLOW(14, false); CRT_ALLOW(14, true); CRT_ALLOW(16, false); CRT_ALLOW(16, true); CRT_ALLOW(24, false); CRT_ALLOW(24, true);
 #undef CRT_ALLOW
+    ok = ok && WideKernels<false, false, false>::allow(dev) && WideKernels<false, false, true>::allow(dev) && WideKernels<false, true, false>::allow(dev) &&
+         WideKernels<false, true, true>::allow(dev);
     return ok ? hipSuccess : hipErrorInvalidValue; // (not fatal for the caller: launch_split falls back to the one-launch form)
 }
 
@@ -1556,6 +1652,16 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
 #define CRT_LAUNCH_SS(CW, SD) do { if (ss) CRT_LAUNCH_RING(CW, SD, true); else CRT_LAUNCH_RING(CW, SD, false); } while (0)
 #define CRT_LAUNCH_SD(CW) do { if (levels == 14) CRT_LAUNCH_SS(CW, 14); else if (levels == 16) CRT_LAUNCH_SS(CW, 16); else if (levels == 24) CRT_LAUNCH_SS(CW, 24); \
                                else CRT_LAUNCH_SS(CW, CRT_STACK_DEPTH); } while (0)
+    if (sc.wide) {
+        if (ra.bvh_depth > 16) return hipErrorInvalidValue; // (crt_api.cpp only widens trees that end up within the 16-level stack)
+        if (a.node_cache == 3) a.node_cache = 2;
+#define CRT_LAUNCH_WIDE(CW, SS) do { if (a.chunk_mode == CM_RING) launch_wide<CW, SS, true>(sc, cam, a, out, ids, counters, blocks, stream, split); \
+                                     else launch_wide<CW, SS, false>(sc, cam, a, out, ids, counters, blocks, stream, split); } while (0)
+        if (count_work) { if (ss) CRT_LAUNCH_WIDE(true, true); else CRT_LAUNCH_WIDE(true, false); }
+        else { if (ss) CRT_LAUNCH_WIDE(false, true); else CRT_LAUNCH_WIDE(false, false); }
+#undef CRT_LAUNCH_WIDE
+        return hipGetLastError();
+    }
     if (count_work) CRT_LAUNCH_SD(true); else CRT_LAUNCH_SD(false);
 #undef CRT_LAUNCH_SD
 #undef CRT_LAUNCH_SS

@@ -51,6 +51,16 @@ CRT_HD int f2i(float f)
 // Node (4 x q4 = 64 B): [c0min.xyz, ref0] [c0max.xyz, ref1] [c1min.xyz, -] [c1max.xyz, -]
 // ref >= 0: index of a node; ref < 0: leaf, ~ref = (first_slot << 3) | (count - 1), count in 1..8.
 // Triangle slot (3 x q4 = 48 B): [a.xyz, prim id] [b.xyz, rank] [c.xyz, material]
+//
+// Four-child node (SceneView.wide; 8 x q4 = 128 B, 7 of them read): [min.x of children 0..3] [min.y] [min.z] [max.x] [max.y] [max.z]
+// [ref 0..3] [-].  Half as many dependent fetches per walk for the same box arithmetic: the format for trees whose nodes do not
+// fit the caches (the 1 M-triangle grid), where a walk waits for memory between node steps.  A reference to such a node carries, above
+// its index, the mask of the children to test (CRT_WIDE_SHIFT): all that exist in the references the builder writes; and when
+// three or four children of a node are hit the walk stores ONE stack entry -- the node itself with the mask of the children still
+// to visit -- and tests those again when it comes back (against a limit that has shrunk since), so the stack holds one entry per
+// level of the wide tree like the two-child walk's, whatever the fan-out.
+#define CRT_WIDE_SHIFT 26
+#define CRT_WIDE_INDEX 0x03FFFFFF
 struct SceneView {
     const q4 *nodes;
     const q4 *tris;
@@ -62,6 +72,7 @@ struct SceneView {
     uint32_t ntris;      // triangle slots
     uint32_t nspheres;   // flat list
     uint32_t sphere_slots; // != 0: some slots of `tris` hold spheres (picks the kernel variant that tests for them)
+    uint32_t wide;         // != 0: `nodes` holds four-child nodes of 128 bytes (trav_inner4_from) instead of two-child nodes of 64
     f3 root_min, root_max;
 };
 
@@ -300,6 +311,70 @@ CRT_HD void trav_inner(const SceneView &sc, Trav &tv, Stack &stack, Counters &cn
     trav_inner_from(src, tv, stack, cnt);
 }
 
+struct GlobalNodes4 {
+    const q4 *nodes;
+    CRT_HD void fetch(uint32_t idx, q4 &mnx, q4 &mny, q4 &mnz, q4 &mxx, q4 &mxy, q4 &mxz, q4 &ref) const
+    {
+        const q4 *n = nodes + 8u * idx;
+        mnx = n[0]; mny = n[1]; mnz = n[2]; mxx = n[3]; mxy = n[4]; mxz = n[5]; ref = n[6];
+    }
+};
+
+// entry / exit time of one child box (pairwise form, as trav_inner_from)
+CRT_HD void slab_times(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, f3 idir, f3 ood, float lo, float hi, float &tn, float &tf)
+{
+    const float ax = fma1(mnx, idir.x, -ood.x), bx = fma1(mxx, idir.x, -ood.x);
+    const float ay = fma1(mny, idir.y, -ood.y), by = fma1(mxy, idir.y, -ood.y);
+    const float az = fma1(mnz, idir.z, -ood.z), bz = fma1(mxz, idir.z, -ood.z);
+    tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), lo));
+    tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), min_no_nan(__builtin_fmaxf(az, bz), hi));
+}
+
+// One four-child node: the children named by the reference's mask are tested, the nearest one that is hit comes next; one other
+// hit child is pushed as it is, two or three as ONE entry (this node, their mask).  Requires is_inner(tv.cur).  Branch-free.
+template <class Nodes, class Stack, class Counters>
+CRT_HD void trav_inner4_from(const Nodes &src, Trav &tv, Stack &stack, Counters &cnt)
+{
+    const uint32_t idx = (uint32_t)tv.cur & CRT_WIDE_INDEX, mask = (uint32_t)tv.cur >> CRT_WIDE_SHIFT;
+    q4 mnx, mny, mnz, mxx, mxy, mxz, rf;
+    src.fetch(idx, mnx, mny, mnz, mxx, mxy, mxz, rf);
+    const int below = stack.peek();
+    cnt.node();
+    const f3 idir = tv.idir, ood = tv.ood;
+    const float lo = -tv.shift, hi = tv.hi;
+    float tn0, tf0, tn1, tf1, tn2, tf2, tn3, tf3;
+    slab_times(mnx.x, mny.x, mnz.x, mxx.x, mxy.x, mxz.x, idir, ood, lo, hi, tn0, tf0);
+    slab_times(mnx.y, mny.y, mnz.y, mxx.y, mxy.y, mxz.y, idir, ood, lo, hi, tn1, tf1);
+    slab_times(mnx.z, mny.z, mnz.z, mxx.z, mxy.z, mxz.z, idir, ood, lo, hi, tn2, tf2);
+    slab_times(mnx.w, mny.w, mnz.w, mxx.w, mxy.w, mxz.w, idir, ood, lo, hi, tn3, tf3);
+    const bool h0 = tn0 <= tf0 && (mask & 1u), h1 = tn1 <= tf1 && (mask & 2u), h2 = tn2 <= tf2 && (mask & 4u), h3 = tn3 <= tf3 && (mask & 8u);
+    const uint32_t hits = (h0 ? 1u : 0u) | (h1 ? 2u : 0u) | (h2 ? 4u : 0u) | (h3 ? 8u : 0u);
+    const int r0 = f2i(rf.x), r1 = f2i(rf.y), r2 = f2i(rf.z), r3 = f2i(rf.w);
+    // the nearest hit child (the lowest index among equals)
+    const float k0 = h0 ? tn0 : FLT_MAX, k1 = h1 ? tn1 : FLT_MAX, k2 = h2 ? tn2 : FLT_MAX, k3 = h3 ? tn3 : FLT_MAX;
+    const bool b01 = k1 < k0, b23 = k3 < k2;
+    const float k01 = b01 ? k1 : k0, k23 = b23 ? k3 : k2;
+    const int r01 = b01 ? r1 : r0, r23 = b23 ? r3 : r2;
+    const uint32_t i01 = b01 ? 2u : 1u, i23 = b23 ? 8u : 4u; // as bits
+    const bool b = k23 < k01 || !(hits & 3u); // (children 0 and 1 both missed: FLT_MAX against FLT_MAX must not pick them)
+    const int next = b ? r23 : r01;
+    const uint32_t pending = hits & ~(b ? i23 : i01);
+    const bool one = (pending & (pending - 1u)) == 0u; // none or one
+    const int other = (pending & 1u) ? r0 : (pending & 2u) ? r1 : (pending & 4u) ? r2 : r3;
+    const int entry = one ? other : (int)((pending << CRT_WIDE_SHIFT) | idx);
+    stack.push_if(entry, pending != 0u);
+    stack.pop_if(hits == 0u);
+    tv.cur = hits == 0u ? below : next;
+}
+
+template <class Stack, class Counters>
+CRT_HD void trav_inner4(const SceneView &sc, Trav &tv, Stack &stack, Counters &cnt)
+{
+    GlobalNodes4 src;
+    src.nodes = sc.nodes;
+    trav_inner4_from(src, tv, stack, cnt);
+}
+
 // One leaf: its 1..8 triangle slots.  Requires tv.cur < 0.
 template <int MODE, class Stack, class Counters>
 CRT_HD void trav_leaf(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Trav &tv, Stack &stack, Counters &cnt)
@@ -328,13 +403,16 @@ CRT_HD void trav_leaf(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, in
     tv.cur = stack.pop();
 }
 
-// One whole walk over spheres + BVH.
-template <int MODE, class Stack, class Counters>
+// One whole walk over spheres + BVH.  WIDE: -1 = as the scene says (host code), 0 / 1 = the caller knows (the kernels are compiled
+// for one node format each).
+template <int MODE, class Stack, class Counters, int WIDE = -1>
 CRT_HD void walk(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Stack &stack, Counters &cnt, Trav &tv)
 {
     trav_begin<MODE>(sc, o, d, tmin, s, after_rank, t_hi, tv, stack, cnt);
+    const bool wide = WIDE < 0 ? sc.wide != 0 : WIDE != 0;
     while (tv.cur != stack_none<Stack>::value) {
-        while (is_inner<stack_none<Stack>::value>(tv.cur)) trav_inner(sc, tv, stack, cnt);
+        if (wide) { while (is_inner<stack_none<Stack>::value>(tv.cur)) trav_inner4(sc, tv, stack, cnt); }
+        else { while (is_inner<stack_none<Stack>::value>(tv.cur)) trav_inner(sc, tv, stack, cnt); }
         if (tv.cur < 0) trav_leaf<MODE>(sc, o, d, tmin, s, after_rank, t_hi, tv, stack, cnt);
     }
 }
@@ -357,7 +435,7 @@ CRT_HD void walk(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int aft
 // hit is being resolved: the fold then needs no registers beyond the shade phase's and nothing is parked in scratch
 // memory -- whose reload, a vector memory load, put an s_waitcnt vmcnt(0) on the COMMON path behind the pixel store);
 // tv.cur is CRT_BVH_NONE again on return.
-template <class Stack, class Counters>
+template <class Stack, class Counters, int WIDE = -1>
 CRT_HD int refold(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float t_min, float &t_hit, int &mat_hit, Stack &stack, Counters &cnt, Search &n,
                   Trav &tv)
 {
@@ -372,7 +450,7 @@ CRT_HD int refold(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float
         float reach = -FLT_MAX;
         for (;;) {
             n.t = 0.0f; n.code = -1; n.mat = 0; n.rank = 0x7FFFFFFF; n.near_tie = false;
-            walk<MODE_NEXT_RANK>(sc, o, d, tmin, n, after, t_hi, stack, cnt, tv);
+            walk<MODE_NEXT_RANK, Stack, Counters, WIDE>(sc, o, d, tmin, n, after, t_hi, stack, cnt, tv);
             if (n.code < 0) break;
             const bool is_tri = (uint32_t)n.code < sc.ntris;
             seen_min = seen_min || n.t == t_min;
@@ -409,7 +487,7 @@ CRT_HD int resolve_hit(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, 
 }
 // The same for a caller whose search `s` and walk state `tv` are free to be used as the fold's working storage (see refold):
 // `s` is consumed, tv.cur must be and stays CRT_BVH_NONE.
-template <class Stack, class Counters>
+template <class Stack, class Counters, int WIDE = -1>
 CRT_HD int resolve_hit_in_place(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, Search &s, float &t_hit, int &mat_hit, Stack &stack, Counters &cnt,
                                 Trav &tv)
 {
@@ -417,7 +495,7 @@ CRT_HD int resolve_hit_in_place(const SceneView &sc, f3 o, f3 d, float tmin, flo
     if (!s.near_tie) { t_hit = s.t; mat_hit = s.mat; return s.t <= tmax ? s.code : -1; }
     cnt.refold();
     const float t_min = s.t;
-    return refold(sc, o, d, tmin, tmax, t_min, t_hit, mat_hit, stack, cnt, s, tv);
+    return refold<Stack, Counters, WIDE>(sc, o, d, tmin, tmax, t_min, t_hit, mat_hit, stack, cnt, s, tv);
 }
 
 // world->hit(ray, Interval(tmin, FLT_MAX), rec) (camera.h:68 -> hittable_list.h:17-63): returns the winning

@@ -109,14 +109,16 @@ int crt_scene_reload_tuning(crt_scene *s);
 
 typedef struct crt_scene_info {
     uint32_t num_triangles, num_spheres, num_materials, num_textures;
-    uint32_t num_nodes;      /* 64-byte two-child nodes          */
-    uint32_t bvh_depth;      /* deepest leaf (root = depth 1)    */
+    uint32_t num_nodes;      /* 64-byte two-child nodes or 128-byte four-child nodes (node_width) */
+    uint32_t bvh_depth;      /* deepest leaf (root = depth 1), in nodes of node_width children    */
     uint32_t max_leaf_size;
     uint32_t device;         /* UINT32_MAX when prepared with CRT_DEVICE_NONE */
     uint64_t node_bytes, triangle_bytes, sphere_bytes; /* resident HBM footprint */
     float bounds_min[3], bounds_max[3];                /* triangle BVH root box  */
     uint32_t builder;        /* 0 = host SAH, 1 = GPU LBVH                                                  */
     float build_ms;          /* GPU LBVH: hipEvent time of the build kernels and the sort; host SAH: wall time */
+    uint32_t node_width;     /* 2; 4 when the scene was committed with CRT_BVH_WIDE=1 in the environment (four-child nodes: an option, slower) */
+    uint32_t binary_depth;   /* depth of the two-child tree the builder made (= bvh_depth when node_width is 2)                          */
 } crt_scene_info;
 int crt_scene_get_info(const crt_scene *s, crt_scene_info *info);
 /* rank[i] = position of primitive i (triangles first, then spheres) in the reference's sorted Morton order

@@ -52,7 +52,7 @@ SceneView host_view(const crt_scene *s, std::vector<Sphere> &spheres)
     spheres = s->flat_spheres;
     SceneView v{};
     v.nodes = s->bvh.nodes.data(); v.tris = s->bvh.tris.data(); v.spheres = spheres.data(); v.shades = s->shades.data(); v.normals = s->normals.data();
-    v.root_ref = s->bvh.root_ref; v.nnodes = (uint32_t)(s->bvh.nodes.size() / 4); v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size(); v.sphere_slots = 1;
+    v.root_ref = s->bvh.root_ref; v.wide = s->bvh.wide ? 1u : 0u; v.nnodes = (uint32_t)(s->bvh.nodes.size() / (s->bvh.wide ? 8 : 4)); v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size(); v.sphere_slots = 1;
     v.root_min = s->bvh.root_box.mn; v.root_max = s->bvh.root_box.mx;
     return v;
 }
@@ -199,6 +199,7 @@ extern "C" int hostsim_entry_point_study(const crt_scene *s, const crt_camera *c
     std::vector<Sphere> spheres;
     const SceneView sc = host_view(s, spheres);
     const CameraPOD &c = *reinterpret_cast<const CameraPOD *>(cam);
+    if (sc.wide) return CRT_ERR_INVALID; // (a study of the two-child format)
     const uint32_t nn = sc.nnodes;
     std::vector<int> parent(nn, -1), depth(nn, 0);
     for (uint32_t n = 0; n < nn; n++) // breadth-first numbering: parents come before children

@@ -557,6 +557,36 @@ def test_work_counters_equal_the_host_single_stepper(hostsim, scenes, gpu_scenes
     assert (st4.rays, st4.nodes, st4.tri_tests, st4.sphere_tests, st4.shaded_hits) == (w4["rays"], w4["nodes"], w4["tri_tests"], w4["sphere_tests"], w4["shaded_hits"])
 
 
+@pytest.mark.parametrize("node_cache_wide", ["0", "2", "4"])
+def test_four_child_nodes_same_frames_half_the_fetches(oracle, hostsim, scenes, capi, monkeypatch, node_cache_wide):
+    """CRT_BVH_WIDE=1 (crt_bvh.h: widen_bvh): the tree collapsed to four children per node is walked by kernels of their own;
+    frames, ids and ray counts are the oracle's, the work counters the host single-stepper's for the same tree."""
+    monkeypatch.setenv("CRT_BVH_WIDE", "1")
+    monkeypatch.setenv("CRT_NODE_CACHE", node_cache_wide)
+    for name, W, H, spp, chunks in (("cats", 200, 113, 3, 0), ("cats", 97, 45, 8, 8), ("random_spheres", 120, 68, 2, 2), ("cat_checker", 64, 36, 4, 2)):
+        desc = getattr(scenes, name)()
+        s = scenes.build(desc, 0)
+        info = s.info()
+        assert info.node_width == 4 and info.bvh_depth <= (info.binary_depth + 1) // 2 + 1 and info.node_bytes == 128 * info.num_nodes
+        params, cam = scenes.make_camera(W)
+        rgb, ids, st = s.render(cam, W, H, spp, want_ids=True, flags=capi.COUNT_WORK, sample_chunks=chunks)
+        fb, rids, _, rst = oracle.RefScene(desc).render(oracle.make_camera(params, W), W, H, spp)
+        if chunks == 0:
+            assert np.array_equal(rgb, fb)
+        assert np.array_equal(ids, rids) and st.rays == rst.rays
+        hs = hostsim.build(desc)
+        want_rgb, want_ids, want = hostsim.render(hs, cam, W, H, spp)
+        got = dict(rays=st.rays, nodes=st.nodes, tri_tests=st.tri_tests, sphere_tests=st.sphere_tests, tie_refolds=st.tie_refolds, shaded_hits=st.shaded_hits)
+        assert got == {k: want[k] for k in got}, (got, want)
+        # the same scene with two children per node: the same frame bit for bit, about twice the node fetches
+        monkeypatch.setenv("CRT_BVH_WIDE", "0")
+        s2 = scenes.build(desc, 0)
+        monkeypatch.setenv("CRT_BVH_WIDE", "1")
+        rgb2, ids2, st2 = s2.render(cam, W, H, spp, want_ids=True, flags=capi.COUNT_WORK, sample_chunks=chunks)
+        assert s2.info().node_width == 2 and np.array_equal(rgb, rgb2) and np.array_equal(ids, ids2)
+        assert st.nodes < 0.75 * st2.nodes and st.tri_tests <= 1.1 * st2.tri_tests
+
+
 @pytest.mark.parametrize("n", [64, 32])
 def test_benchmarked_configuration_at_full_size(scenes, gpu_scenes, capi, n):
     """What bench.py times: cats, 1920x1080, 64 spp, sample_chunks = 64 (one sample per work unit; 32 was the default before

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(capi):
 
 def test_struct_layouts_match_header(capi):
     assert C.sizeof(capi.Camera) == 136 and C.sizeof(capi.RenderParams) == 56 and C.sizeof(capi.Stats) == 136
-    assert C.sizeof(capi.SceneInfo) == 88
+    assert C.sizeof(capi.SceneInfo) == 96
 
 
 def test_render_without_device_fails_loudly(capi, scenes):
@@ -83,7 +83,7 @@ def test_bvh_shape(capi, scenes):
         info = scenes.build(getattr(scenes, name)(), capi.DEVICE_NONE).info()
         assert info.num_triangles == ntri and info.num_spheres == 2
         assert 1 <= info.max_leaf_size <= 4 and info.bvh_depth <= 32
-        assert info.node_bytes == 64 * info.num_nodes and info.triangle_bytes == 48 * ntri
+        assert info.node_bytes == 32 * info.node_width * info.num_nodes and info.triangle_bytes == 48 * ntri
         assert ntri / 4 <= info.num_nodes + 1 <= ntri
         # root box = triangles only: the radius-1000 ground sphere does not inflate the tree (F10)
         assert max(abs(x) for x in list(info.bounds_min) + list(info.bounds_max)) < 10
@@ -219,6 +219,41 @@ def test_ties_resolve_in_reference_leaf_order(hostsim, oracle, capi):
     fb, ids, _, st = rs.render(rc, 64, 36, 4)
     out, oid, hs = hostsim.render(s, cam, 64, 36, 4)
     assert np.array_equal(ids, oid) and np.array_equal(fb, out) and st.rays == hs["rays"] and hs["tie_refolds"] > 0
+
+
+def test_four_child_nodes_on_the_host(hostsim, oracle, capi, scenes, monkeypatch):
+    """CRT_BVH_WIDE=1 (crt_bvh.h: widen_bvh; crt_traverse.h: trav_inner4_from): the collapsed tree walked by the product code on the
+    host gives the oracle's frames -- tie scene included, where the fold in leaf order decides every hit -- with about half the
+    node fetches, at most one stack entry per level of the wide tree."""
+    monkeypatch.setenv("CRT_BVH_WIDE", "1")
+    for name, W, H, spp in (("cats", 160, 90, 2), ("random_spheres", 96, 54, 2)):
+        desc = getattr(scenes, name)()
+        s = hostsim.build(desc)
+        info = s.info()
+        assert info.node_width == 4 and info.node_bytes == 128 * info.num_nodes and info.bvh_depth < info.binary_depth
+        params, cam = scenes.make_camera(W)
+        fb, ids, _, st = oracle.RefScene(desc).render(oracle.make_camera(params, W), W, H, spp)
+        out, oid, hs = hostsim.render(s, cam, W, H, spp)
+        assert np.array_equal(ids, oid) and np.array_equal(fb, out) and st.rays == hs["rays"]
+        assert hs["max_stack"] <= info.bvh_depth
+        monkeypatch.setenv("CRT_BVH_WIDE", "0")
+        two = hostsim.render(hostsim.build(desc), cam, W, H, spp)[2]
+        monkeypatch.setenv("CRT_BVH_WIDE", "1")
+        assert hs["nodes"] < 0.75 * two["nodes"] and hs["tri_tests"] <= 1.1 * two["tri_tests"]
+    desc = _tie_scene(capi)
+    s = hostsim.build(desc)
+    assert s.info().node_width == 4
+    rs = oracle.RefScene(desc)
+    rng = np.random.default_rng(5)
+    took_any = 0
+    for _ in range(300):
+        o = np.array([rng.uniform(-0.8, 0.8), rng.uniform(-0.8, 0.8), 1.0], np.float32)
+        d = np.array([rng.uniform(-0.05, 0.05), rng.uniform(-0.05, 0.05), -1.0], np.float32)
+        ref_prim, ref_t = rs.trace(o, d)
+        prim, t, took = hostsim.trace(s, o, d)
+        assert prim == ref_prim and (ref_prim < 0 or t == ref_t), (o, d)
+        took_any += took
+    assert took_any > 50
 
 
 def test_tile_partition_covers_frame_exactly_once(hostsim, scenes):

@@ -18,14 +18,22 @@ for ranks in (1, 2, 4, 8):
     for mode, name in ((capi.MULTI_TILE, "tile"), (capi.MULTI_SAMPLE, "sample")):
         s = _commit(scenes, capi, desc, [0] * ranks)
         stream = torch.cuda.Stream()
+        enqueue = []
         def go(n):
             for k in range(n):
+                t = time.perf_counter()
                 s.render(cam, W, H, spp, out_rgb=out[k % 2].data_ptr(), want_stats=False, stream=stream.cuda_stream, sample_chunks=32,
                          flags=capi.OUT_DEVICE, multi=mode)
+                enqueue.append(time.perf_counter() - t)
             stream.synchronize()
         go(3)
+        del enqueue[:]
         t0 = time.perf_counter(); go(frames); dt = time.perf_counter() - t0
         res["%s x%d" % (name, ranks)] = round(dt / frames * 1e3, 3)
+        # the host's share: the time the asynchronous call itself takes (it returns when everything is enqueued; once the queues are
+        # full it also waits for room, so the median and the first calls after a sync tell more than the mean)
+        enqueue.sort()
+        res["%s x%d enqueue ms (min / median)" % (name, ranks)] = [round(enqueue[0] * 1e3, 3), round(enqueue[len(enqueue) // 2] * 1e3, 3)]
         s.close()
 s = scenes.build(desc, 0)
 streams = [torch.cuda.Stream(), torch.cuda.Stream()]
