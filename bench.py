@@ -44,28 +44,28 @@ VALU_PEAK_TLANEOPS_256CU = 256 * 4 * 32 * 2.4e9 / 1e12
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0          # aggregate L2, same guide
 INFINITY_CACHE_GATHER_GBS = 8600.0  # random 1 KB-row gathers from a 38 MB table (Infinity Cache resident), same guide
-# One sample per chunk at the headline's 64 spp: the finalize pass then adds single samples in sample order, which is the
-# reference's own loop (renderer.h:26-32), so the timed frame is bit-identical to the whole-pixel one
+# Default: one sample per work unit, whatever the workload's sample count: the samples of a pixel are then added singly in sample
+# order, which is the reference's own loop (renderer.h:26-32), so the timed frame is bit-identical to the whole-pixel one
 # (tests/test_gpu.py::test_one_sample_per_chunk_is_the_sequential_sum, also at the full 1080p x 64 spp).  Same for every N.
-DEFAULT_CHUNKS = 64
+# (The library decides per frame whether the units' results go through slabs or the waves' rings: crt_api.cpp, plan_chunks.)
 
 
-def lane_ops(st):
-    # 30 per box test (2 per node), 60 per triangle test, 25 per sphere test, 120 per shaded bounce
-    return 30.0 * 2 * st.nodes + 60.0 * st.tri_tests + 25.0 * st.sphere_tests + 120.0 * st.shaded_hits
+def lane_ops(st, node_width=2):
+    # 30 per box test (2 per node; 4 with CRT_BVH_WIDE=1), 60 per triangle test, 25 per sphere test, 120 per shaded bounce
+    return 30.0 * node_width * st.nodes + 60.0 * st.tri_tests + 25.0 * st.sphere_tests + 120.0 * st.shaded_hits
 
 
-def algorithmic_bytes(st, width, height):
-    return 64.0 * st.nodes + 48.0 * st.tri_tests + 32.0 * st.sphere_tests + 12.0 * width * height
+def algorithmic_bytes(st, width, height, node_width=2):
+    return 32.0 * node_width * st.nodes + 48.0 * st.tri_tests + 32.0 * st.sphere_tests + 12.0 * width * height
 
 
 def pmc_traffic(workload, world):
     """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes of this same command
     (profiles/run_rocprof.sh: FETCH_SIZE and WRITE_SIZE in their own runs; tools/summarize_prof.py applies the guide's
     unit and gfx950 corrections): the newest profiles/<dir>/pmc_render_kernel.json whose bench line was this workload on
-    one GPU.  None when there is none."""
+    one GPU, and where it came from.  (None, None) when there is none."""
     if world != 1:
-        return None
+        return None, None
     root = os.path.join(REPO, "profiles")
     best = None
     def natural(name):  # r2_v10_... after r2_v9_...
@@ -82,11 +82,11 @@ def pmc_traffic(workload, world):
         except (KeyError, ValueError, OSError, IndexError):
             continue
     if not best:
-        return None
+        return None, None
     try:
-        return float(json.load(open(best))["derived"]["hbm_bytes_per_launch"])
+        return float(json.load(open(best))["derived"]["hbm_bytes_per_launch"]), "profiles/%s (committed PMC pass)" % os.path.basename(os.path.dirname(best))
     except (KeyError, ValueError, OSError):
-        return None
+        return None, None
 
 
 def cpu_baseline(desc, cam_params, width, height, max_depth, seed, target_seconds=4.0, reps=3):
@@ -126,7 +126,8 @@ def image_note(chunks, unit_spp, sample_split=False):
         return ("bit-exact: one sample per work unit, the %d single-sample slabs of a pixel added in sample order starting from 0 -- the float "
                 "operations of the reference's loop (renderer.h:26-32); equal to the whole-pixel frame bit for bit, tested at this size" % chunks)
     return ("chunked-sum variant: same samples, each pixel's %d chunk sums added in chunk order; differs from the reference's sequential "
-            "sample-order sum by float association only (<= 3e-7 relative, tests/test_gpu.py); --chunks 1 or --chunks <spp> are bit-exact" % chunks)
+            "sample-order sum by float association only (<= 3e-7 relative, tests/test_gpu.py); --chunks 1 and the default (one sample per "
+            "unit) are bit-exact" % chunks)
 
 
 def main():
@@ -144,7 +145,8 @@ def main():
     ap.add_argument("--spp", type=int, default=0, help="override samples per pixel (debug; invalidates the headline number)")
     ap.add_argument("--chunks", type=int, default=-1,
                     help="sample chunks per pixel (crt_render_params.sample_chunks): work unit = (pixel, spp/chunks samples); "
-                         "1 = whole pixel per lane, bit-exact sample-order sum; default: DEFAULT_CHUNKS")
+                         "1 = whole pixel per lane; default: one sample per unit (= spp); both are the bit-exact sample-order sum; "
+                         "any other value is lowered to a divisor of spp")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -171,9 +173,9 @@ def main():
     cam_params, cam = scenes.make_camera(W, **cam_over)
     info = scene.info()
 
-    chunks = DEFAULT_CHUNKS if args.chunks < 0 else max(args.chunks, 1)
+    chunks = spp if args.chunks < 0 else min(max(args.chunks, 1), spp)
     while spp % chunks:
-        chunks //= 2
+        chunks -= 1
     if args.mode == "tile":
         frame = TileFrame(W, H, world, rank, device, sample_chunks=chunks, pipelined=in_flight if in_flight > 1 else False)
 
@@ -247,9 +249,9 @@ def main():
         cus = props.multi_processor_count
         valu_peak = VALU_PEAK_TLANEOPS_256CU * cus / 256.0
         ksec = kernel_avg_ms / 1e3
-        ops = lane_ops(stw)
-        traffic = pmc_traffic(args.workload, world)
-        abytes = algorithmic_bytes(stw, W, H)
+        ops = lane_ops(stw, info.node_width)
+        traffic, traffic_source = pmc_traffic(args.workload, world)
+        abytes = algorithmic_bytes(stw, W, H, info.node_width)
         used_chunks = chunks if args.mode == "tile" else frame.sample_chunks
         out = {
             "metric": "Mrays/s (all bounces)", "value": rays_frame * args.steps / elapsed / 1e6, "unit": "Mrays/s",
@@ -259,10 +261,10 @@ def main():
                        (args.workload, W, H, spp, depth, {"cats": "cats.obj", "random_spheres": "no mesh"}.get(builder, "cat.obj"), seed),
                        "partition": "%s x%d" % (args.mode, world), "frames_in_flight": frame.slots.in_flight, "sample_chunks": used_chunks,
                        "image": image_note(used_chunks, spp if args.mode == "tile" else spp // world, args.mode == "sample" and world > 1),
-                       "triangles": info.num_triangles, "bvh_nodes": info.num_nodes, "bvh_depth": info.bvh_depth,
+                       "triangles": info.num_triangles, "bvh_nodes": info.num_nodes, "bvh_depth": info.bvh_depth, "bvh_node_width": info.node_width,
                        "rays_per_frame": int(rays_frame), "device_cus": cus},
             "roofline": {"bound": "valu", "achieved": ops / ksec / 1e12, "peak": valu_peak, "unit": "Tlane-op/s",
-                         "frac": ops / ksec / 1e12 / valu_peak, "traffic": traffic,
+                         "frac": ops / ksec / 1e12 / valu_peak, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "render_kernel", "kernel_ms": kernel_avg_ms, "kernel_ms_note": "mean of 3 launches that run alone, right after the timed region",
                          "per_step": {"kernel_end_to_end_ms": end_to_end_ms, "frac": ops / (end_to_end_ms / 1e3) / 1e12 / valu_peak,
                                       "note": "mean distance between the ends of consecutive frames' render work in the timed region (HIP events on the "
@@ -276,7 +278,7 @@ def main():
                                  "note": "achieved = PMC HBM bytes per launch (traffic) / kernel time; the algorithmic bytes are priced in l2_lds"},
                          "l2_lds": {"bound": "l2", "achieved": abytes / ksec / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": abytes / ksec / 1e9 / L2_PEAK_GBS,
                                     "infinity_cache_gather_peak": INFINITY_CACHE_GATHER_GBS, "frac_of_infinity_cache_gather": abytes / ksec / 1e9 / INFINITY_CACHE_GATHER_GBS,
-                                    "note": "algorithmic node (64 B) + triangle (48 B) + sphere (32 B) + framebuffer bytes / kernel time: a request rate served by the "
+                                    "note": "algorithmic node (64 B; 128 B with four children) + triangle (48 B) + sphere (32 B) + framebuffer bytes / kernel time: a request rate served by the "
                                             "LDS node copy, L1 and L2 when the scene (%d KiB) is cache resident; for scenes beyond L2 (the 1 M-triangle grid) the "
                                             "Infinity-Cache gather rate is the memory-side bound"
                                             % ((info.node_bytes + info.triangle_bytes + info.sphere_bytes) // 1024)}},

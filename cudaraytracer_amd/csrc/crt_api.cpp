@@ -16,6 +16,10 @@
 #include <utility>
 #include <vector>
 
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <thread>
 #include "crt_bvh.h"
 #include "crt_kernels.h"
 #include "crt_lbvh.h"
@@ -353,8 +357,36 @@ struct MultiRank {
     bool sent_recorded[2] = { false, false };
     void *comm = nullptr;                                               // ncclComm_t (RCCL transport)
 };
+// crt_render_multi's rank workers: one thread per logical rank beyond the first, started by crt_scene_commit_devices.  A frame's
+// per-rank part of the enqueue (a dozen HIP calls: waits, counters, one or two launches with their fork / join, events) is issued
+// by the rank's own thread, rank 0's by the caller's, so the host's time per frame is one rank's, not n ranks' (measured with 8
+// logical ranks).  The exchange and the epilogue stay on the caller's thread.
+struct RankWorkers {
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable wake, done;
+    uint64_t generation = 0;
+    uint32_t pending = 0;
+    bool stop = false;
+    const std::function<int(uint32_t)> *job = nullptr;
+    std::vector<int> rc;
+    std::vector<std::string> msg;
+    explicit RankWorkers(uint32_t n) : rc(n, 0), msg(n)
+    {
+        for (uint32_t r = 1; r < n; r++) threads.emplace_back([this, r] { run(r); });
+    }
+    ~RankWorkers()
+    {
+        { std::lock_guard<std::mutex> l(mu); stop = true; }
+        wake.notify_all();
+        for (std::thread &t : threads) t.join();
+    }
+    void run(uint32_t r);
+    int run_all(const std::function<int(uint32_t)> &j); // j(r) for every rank; the first failure, with its message
+};
 struct MultiState {
     bool ready = false, use_rccl = false, peer_ids = false;
+    std::unique_ptr<RankWorkers> workers;                               // null: the caller's thread issues every rank (CRT_MULTI_THREADS=0, or one rank)
     std::vector<MultiRank> rank;
     float *d_stage_rgb = nullptr; size_t stage_rgb_floats = 0;          // root: staging of host-pointer frames
     int *d_stage_ids = nullptr; size_t stage_ids = 0;
@@ -1079,9 +1111,50 @@ Rccl g_rccl;
         if (r_ != ncclSuccess) return fail(CRT_ERR_HIP, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
     } while (0)
 
+void RankWorkers::run(uint32_t r)
+{
+    uint64_t seen = 0;
+    for (;;) {
+        const std::function<int(uint32_t)> *j;
+        {
+            std::unique_lock<std::mutex> l(mu);
+            wake.wait(l, [&] { return stop || generation != seen; });
+            if (stop) return;
+            seen = generation;
+            j = job;
+        }
+        const int code = (*j)(r);
+        std::lock_guard<std::mutex> l(mu);
+        rc[r] = code;
+        if (code) msg[r] = g_error; // (the error text is per thread: hand it to the caller's)
+        if (--pending == 0) done.notify_one();
+    }
+}
+
+int RankWorkers::run_all(const std::function<int(uint32_t)> &j)
+{
+    {
+        std::lock_guard<std::mutex> l(mu);
+        job = &j;
+        pending = (uint32_t)threads.size();
+        generation++;
+    }
+    wake.notify_all();
+    const int rc0 = j(0);
+    {
+        std::unique_lock<std::mutex> l(mu);
+        done.wait(l, [&] { return pending == 0; });
+    }
+    if (rc0) return rc0;
+    for (size_t r = 1; r < rc.size(); r++)
+        if (rc[r]) return fail(rc[r], msg[r]);
+    return CRT_OK;
+}
+
 void crt_scene::release_multi()
 {
     MultiState &m = multi;
+    m.workers.reset(); // (no frame is being enqueued: the threads are idle)
     for (size_t r = 0; r < m.rank.size(); r++) {
         MultiRank &k = m.rank[r];
         if (r < dev.size() && dev[r].device >= 0) (void)hipSetDevice(dev[r].device);
@@ -1163,6 +1236,12 @@ extern "C" int crt_scene_commit_devices(crt_scene *s, const int *devices, uint32
         if (r_ != ncclSuccess) return bail(fail(CRT_ERR_HIP, std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r_)));
         for (uint32_t r = 0; r < n; r++) m.rank[r].comm = comms[r];
     }
+    // Rank workers when every rank has a device of its own (CRT_MULTI_THREADS=1 / 0 forces / forbids).  Logical ranks that share a GPU
+    // -- the one-GPU rehearsal -- are issued by the caller's thread: eight threads feeding one device mostly wait for each other
+    // inside the runtime (8 ranks on one MI355X: 0.46 -> 0.25 ms per call at best, median 1.15 -> 0.70), and the order in which the
+    // ranks' launches reach that GPU then varies from frame to frame (9.9 -> 10.7 ms per frame).
+    const int threads = get_env_int("CRT_MULTI_THREADS", -1);
+    if (n > 1 && (threads > 0 || (threads < 0 && distinct))) m.workers.reset(new RankWorkers(n));
     m.ready = true;
     return CRT_OK;
 }
@@ -1241,9 +1320,9 @@ extern "C" int crt_render_multi(const crt_scene *cs, const crt_camera *cam, cons
     m.frames++;
     HIP_TRY(hipEventRecord(m.fork, user)); // what the caller has enqueued on its stream so far
 
-    // ---- every rank renders its part on its own stream ----
+    // ---- every rank renders its part on its own stream, enqueued by its own thread ----
     std::vector<StreamScratch *> x(n, nullptr);
-    for (uint32_t r = 0; r < n; r++) {
+    const std::function<int(uint32_t)> enqueue_rank = [&](uint32_t r) -> int {
         MultiRank &k = m.rank[r];
         HIP_TRY(hipSetDevice(s->dev[r].device));
         hipStream_t st = k.stream[set];
@@ -1253,13 +1332,19 @@ extern "C" int crt_render_multi(const crt_scene *cs, const crt_camera *cam, cons
         if (out_ids) HIP_TRY(hipStreamWaitEvent(st, m.fork, 0));
         // this set's previous frame (two frames ago): its parts on the root have been consumed once that frame was complete
         if (m.done_recorded[set]) HIP_TRY(hipStreamWaitEvent(st, m.frame_done[set], 0));
-        if ((rc = acquire_scratch(s, s->dev[r], st, &q[r], rank_chunks, &x[r]))) return rc;
+        int rc_ = acquire_scratch(s, s->dev[r], st, &q[r], rank_chunks, &x[r]);
+        if (rc_) return rc_;
         q[r].stream = st;
-        if ((rc = enqueue_render(s, s->dev[r], cam, &q[r], rank_chunks, k.d_local[set], d_ids, x[r]->d_counters, x[r]->d_chunks, x[r]->plan, x[r]->ev0, x[r]->ev1, st, &x[r]->split)))
-            return rc;
+        if ((rc_ = enqueue_render(s, s->dev[r], cam, &q[r], rank_chunks, k.d_local[set], d_ids, x[r]->d_counters, x[r]->d_chunks, x[r]->plan, x[r]->ev0, x[r]->ev1, st, &x[r]->split)))
+            return rc_;
         HIP_TRY(hipEventRecord(x[r]->ev_done, st));
         x[r]->recorded = true;
-    }
+        return CRT_OK;
+    };
+    if (m.workers) rc = m.workers->run_all(enqueue_rank);
+    else for (uint32_t r = 0; r < n && !rc; r++) rc = enqueue_rank(r);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(root));
 
     // ---- ONE exchange: the parts travel to the root ----
     float *d_all = m.rank[0].d_all[set];

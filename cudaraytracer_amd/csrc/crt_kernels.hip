@@ -1315,7 +1315,8 @@ hipError_t launch_finalize_chunks(const float *slabs, uint32_t chunks, size_t n,
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Static scratch of crt_render_noalloc (include/crt.h): counters + chunk slabs for callers that may not allocate.
+// Static scratch of crt_render_noalloc (include/crt.h): counters, then the frame's chunk slabs [pixel][chunk][3] or the waves' rings
+// (crt_kernels.h: CM_SLAB / CM_RING), for callers that may not allocate.
 // `scratch` is a host-side stand-in for the symbol, not a device address: host code only ever uses the per-device
 // address hipGetSymbolAddress returned, taken once per device with that device current (each GPU holds its own copy of
 // the array at its own address) and handed to the kernels as an argument like any other buffer.
@@ -1379,7 +1380,7 @@ static bool launch_whole_tree(const SceneView &sc, const CameraPOD &cam, const R
 // 80 of the CU's 160 KB of LDS are stacks.  A workgroup cannot have more than 16 waves, so a CU gets ONE 16-wave workgroup whose
 // LDS copy holds the whole node array of a small tree (1328 nodes beside a 14-level stack, 1176 beside 16 levels) and ONE 4-wave
 // workgroup with a small copy: two launches on two streams that take their work from the same block counters of the same frame,
-// 16 + 4 = the same 20 waves per CU (4 x 104 + 96 registers per SIMD lane).  On the headline frame no wave of the large
+// 16 + 4 = the same 20 waves per CU (both kernels at 96 registers: five waves per SIMD, see render_kernel_dyn).  On the headline frame no wave of the large
 // workgroup ever fetches a node from device memory: 8.33 ms per step against 8.87.  Both launches are the
 // same kernel with other template arguments, so the frame is the same bit for bit.  The small copy must stay below 32 KB per
 // workgroup: above it the compiler sees an LDS-limited occupancy of 4 waves per SIMD, gives the kernel 128 registers, and the
@@ -1404,6 +1405,16 @@ static bool allow_dynamic_lds(Kernel kernel, size_t bytes, std::atomic<uint64_t>
     }
     done.fetch_or(1ull << dev, std::memory_order_relaxed);
     return true;
+}
+
+// A two-launch frame whose launches went out but whose join could not be enqueued: the frame must not be launched again in another
+// form (it is rendering), and the caller's stream does not wait for the helper's half -- launch_render returns this as its error.
+static thread_local hipError_t g_join_error = hipSuccess;
+static void join_split(hipStream_t stream, const SplitStreams *split)
+{
+    hipError_t e = hipEventRecord(split->join, split->helper);
+    if (e == hipSuccess) e = hipStreamWaitEvent(stream, split->join, 0);
+    if (e != hipSuccess) g_join_error = e;
 }
 
 // The kernels of a two-launch frame for a stack of SD levels and what LDS they ask for at launch (see launch_split).
@@ -1452,7 +1463,7 @@ static bool launch_split(const SceneView &sc, const CameraPOD &cam, const Render
             hipLaunchKernelGGL(K::large(SD != 24 && sc.nnodes <= (uint32_t)NA), dim3(cus), dim3(1024), K::large_lds, stream, sc, cam, a, out, ids, counters);
             hipLaunchKernelGGL(K::small(), dim3(cus), dim3(256), K::small_lds, split->helper, sc, cam, b, out, ids, counters);
         }
-        if (hipEventRecord(split->join, split->helper) != hipSuccess || hipStreamWaitEvent(stream, split->join, 0) != hipSuccess) return false;
+        join_split(stream, split);
         return true;
     }
     return false;
@@ -1515,8 +1526,7 @@ static void launch_wide(const SceneView &sc, const CameraPOD &cam, const RenderA
             hipLaunchKernelGGL(K::large(), dim3(cus), dim3(1024), K::large_lds, stream, sc, cam, a, out, ids, counters);
             hipLaunchKernelGGL(K::small(), dim3(cus), dim3(256), K::small_lds, split->helper, sc, cam, b, out, ids, counters);
         }
-        (void)hipEventRecord(split->join, split->helper);
-        (void)hipStreamWaitEvent(stream, split->join, 0);
+        join_split(stream, split);
         return;
     }
     if (a.node_cache) {
@@ -1610,6 +1620,7 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
     const uint32_t ntiles = ra.tiles_x * ra.tiles_y;
     const uint32_t local_tiles = (ntiles + ra.tile_ranks - 1 - ra.tile_rank) / ra.tile_ranks; // tiles k = b*ranks + rank < ntiles
     if (local_tiles == 0) return hipSuccess;
+    g_join_error = hipSuccess;
     RenderArgs a = ra;
     a.local_pixels = local_tiles * 64u;
     if (a.chunks <= 1) { a.chunks = 1; a.chunk_mode = CM_WHOLE; }
@@ -1660,13 +1671,13 @@ hipError_t launch_render(const SceneView &sc, const CameraPOD &cam, const Render
         if (count_work) { if (ss) CRT_LAUNCH_WIDE(true, true); else CRT_LAUNCH_WIDE(true, false); }
         else { if (ss) CRT_LAUNCH_WIDE(false, true); else CRT_LAUNCH_WIDE(false, false); }
 #undef CRT_LAUNCH_WIDE
-        return hipGetLastError();
+        return g_join_error != hipSuccess ? g_join_error : hipGetLastError();
     }
     if (count_work) CRT_LAUNCH_SD(true); else CRT_LAUNCH_SD(false);
 #undef CRT_LAUNCH_SD
 #undef CRT_LAUNCH_SS
 #undef CRT_LAUNCH_RING
-    return hipGetLastError();
+    return g_join_error != hipSuccess ? g_join_error : hipGetLastError();
 }
 
 bool pool_kernel_built()

@@ -178,9 +178,10 @@ class SampleFrame:
             raise ValueError("total_spp must be a multiple of the world size")
         self.width, self.height, self.world, self.rank, self.total_spp = width, height, world, rank, total_spp
         self.spp_local = total_spp // world
-        self.sample_chunks = sample_chunks
+        # a rank's share of the samples must divide into the chunks; one sample per unit (chunks = total_spp) stays one sample per unit
+        self.sample_chunks = self.spp_local if sample_chunks >= total_spp else min(sample_chunks, self.spp_local)
         while self.sample_chunks > 1 and self.spp_local % self.sample_chunks:
-            self.sample_chunks //= 2
+            self.sample_chunks -= 1
         self.slots = _Slots(device, pipelined)
         self._dev_flag = capi.OUT_DEVICE if self.slots.gpu else 0
         nbuf = self.slots.n

@@ -103,7 +103,8 @@ int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags);
  * CRT_MULTI_TRANSPORT=copy forces the copies).  n <= 64. */
 int crt_scene_commit_devices(crt_scene *s, const int *devices, uint32_t n, uint32_t flags);
 /* The library reads its tuning knobs from the environment (CRT_KERNEL, CRT_SCHED_THRESHOLD, CRT_POOL_REFILL,
- * CRT_NODE_CACHE, CRT_STRIPE_BANDS, CRT_WAVES_PER_CU, CRT_PRINT_SECTIONS) once, at commit, not per frame; this reads
+ * CRT_NODE_CACHE, CRT_STRIPE_BANDS, CRT_WAVES_PER_CU, CRT_PRINT_SECTIONS, CRT_CHUNK_MODE, CRT_SLAB_BUDGET_MB, CRT_RING_SLOTS,
+ * CRT_RING_BATCH, CRT_FETCH_BLOCK; CRT_BVH_WIDE and CRT_MAX_LEAF shape the tree and only count at commit) once, at commit, not per frame; this reads
  * them again for a committed scene (tuning runs and tests that switch kernel variants between frames). */
 int crt_scene_reload_tuning(crt_scene *s);
 
@@ -156,24 +157,29 @@ typedef struct crt_render_params {
     uint32_t flags;
     uint32_t ids_sample;          /* which sample's primary-hit ids go to out_ids                           */
     uint32_t sample_chunks;       /* 0 or 1: a lane renders all spp samples of its pixel, summed in sample order
-                                     (renderer.h:28-32), bit for bit.  n > 1 (a power of two dividing spp): the work unit is (pixel, chunk of
+                                     (renderer.h:28-32), bit for bit.  n > 1 (any divisor of spp): the work unit is (pixel, chunk of
                                      spp/n consecutive samples), each chunk summed in sample order, the n chunk sums added in
                                      chunk order starting from 0: same samples, finer load balance.  n = spp (one sample per
-                                     unit) adds single samples in sample order, i.e. it is the sequential sum again, bit for
-                                     bit -- the fast exact setting; 1 < n < spp differs from it by float association only   */
+                                     unit, whatever spp is: 10, 12, 100 ...) adds single samples in sample order, i.e. it is the
+                                     sequential sum again, bit for bit -- the fast exact setting; 1 < n < spp differs from it by
+                                     float association only.  Where the chunk sums wait is the library's choice per frame: slabs
+                                     [pixel][chunk][3] added up by a second kernel while they fit CRT_SLAB_BUDGET_MB (2048), else
+                                     per-wave rings in which the wave that rendered a block of pixels adds it up itself (bounded
+                                     memory whatever the frame: 4K x 1024 spp works); CRT_CHUNK_MODE=1 / 2 forces one.  Same bits. */
     uint64_t seed;                /* Philox key; reference seed literal 1984 (renderer.h:45)                */
     void *stream;                 /* hipStream_t, NULL = default stream                                     */
 } crt_render_params;
 
 typedef struct crt_stats {
     uint64_t rays;          /* path segments traced = world->hit() calls (camera.h:68)                      */
-    uint64_t nodes;         /* 64-byte nodes fetched            (CRT_COUNT_WORK)                            */
+    uint64_t nodes;         /* nodes fetched (64-byte; 128-byte with CRT_BVH_WIDE=1)  (CRT_COUNT_WORK)      */
     uint64_t tri_tests;     /* 48-byte triangle records tested  (CRT_COUNT_WORK)                            */
     uint64_t sphere_tests;  /* 32-byte sphere records tested    (CRT_COUNT_WORK)                            */
     uint64_t tie_refolds;   /* rays that took the exact reference-order tie fold                            */
     uint64_t shaded_hits;   /* rays that hit something and were shaded (CRT_COUNT_WORK)                     */
     uint64_t sched[10];     /* schedule counters (CRT_COUNT_WORK): [0] shade-phase runs [1] lanes in them [2] longest wave
-                               lifetime, 10 ns ticks [4] node steps [5] lanes in them [6] leaf steps [7] lanes in them
+                               lifetime, 10 ns ticks [3] lane-passes spent waiting for a ring slot (ring mode) [4] node steps
+                               [5] lanes in them [6] leaf steps [7] lanes in them
                                [8] waves that rendered pixels [9] sum of their lifetimes, 10 ns ticks               */
     float kernel_ms;        /* hipEvent time of the render kernel alone (not the chunk-sum pass) on `stream` */
     uint32_t reserved;
@@ -185,6 +191,8 @@ typedef struct crt_stats {
  * `ids_sample` (-1 = miss).  Both may be device pointers (any HIP allocation on the scene's device) or host
  * pointers (staged through an internal device buffer).  With stats != NULL the call synchronises `stream`
  * before returning; with stats == NULL and device pointers it is asynchronous on `stream`.
+ * (A render wave that left through its trip-counter guard -- a scheduling bug, never seen -- is reported as CRT_ERR_HIP by the
+ * calls that read the counters back, i.e. with stats != NULL; asynchronous calls and crt_render_noalloc cannot report it.)
  * Calls on one stream run in order.  Calls on different streams may overlap on the GPU, and may come from different host
  * threads (one thread per stream; everything else about a handle stays single-threaded): the scene keeps one set of
  * scratch buffers (work counters, chunk slabs, the staging of host-pointer frames) per stream, up to four sets; a fifth
@@ -195,14 +203,18 @@ int crt_render(const crt_scene *s, const crt_camera *cam, const crt_render_param
 
 /* crt_render for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc.  (No counterpart in the reference, whose Renderer allocates and frees per frame, renderer.h:55-72.)
- * Same frame, same kernels, same bits as crt_render, but the work counters and the sample-chunk slabs live in a static
- * __device__ array of the library (16.6 KB of counters + CRT_NOALLOC_SLAB_BYTES = 32 MiB of slabs, one copy per GPU the
- * library runs on, held until the process ends) whose per-device address is taken when a scene is committed to the
+ * Same frame, same kernels, same bits as crt_render, but the work counters and the sample-chunk scratch live in a static
+ * __device__ array of the library (16.6 KB of counters + CRT_NOALLOC_SLAB_BYTES = 32 MiB for slabs or rings, one copy per
+ * GPU the library runs on, held until the process ends) whose per-device address is taken when a scene is committed to the
  * device.  The call makes no hipMalloc / hipFree / stream or event creation and never waits on the host: everything is
  * enqueued on p->stream (a large frame runs as two launches, the second on a helper stream of the scene that is forked from
  * and joined to p->stream by two events; stream and events are made at commit).  out_rgb and out_ids (nullable) must be device pointers; out_rays (nullable, device pointer) receives the
- * frame's path-segment count.  Limits: with sample_chunks > 1, output pixels (rounded up to a multiple of 64) x 3 x sample_chunks x 4 bytes
- * must fit the 32 MiB of slabs (CRT_ERR_LIMIT otherwise; sample_chunks <= 1 needs no slab and has no size limit).  There is no
+ * frame's path-segment count.  Limits: with sample_chunks > 1 the frame takes slabs when output pixels (rounded up to a
+ * multiple of 64) x 3 x sample_chunks x 4 bytes fit the 32 MiB, else per-wave rings: (persistent waves + 16) x ring slots
+ * (4, lowered to 2 if need be) x block x 12 bytes must fit, a block being the samples of whole pixels, 65 to 128 of them (spp itself
+ * from 128 on) -- on a 256-CU device that admits
+ * any frame size up to 256 samples per pixel (1920 x 1080 x 64 with sample_chunks = 64: 31.6 MB); CRT_ERR_LIMIT otherwise.
+ * sample_chunks <= 1 needs no scratch and has no limit.  There is no
  * crt_stats and no CRT_COUNT_WORK readout.  Every call on a GPU shares that GPU's array: the call clears what must start
  * at zero, and two calls whose kernels overlap on one GPU (different streams) race -- keep them on one stream. */
 #define CRT_NOALLOC_SLAB_BYTES (32u << 20)
@@ -222,7 +234,9 @@ int crt_render_noalloc(const crt_scene *s, const crt_camera *cam, const crt_rend
  * (nullable, device pointer on devices[0] or host): every rank writes the ids of its own pixels / sample straight into
  * the root's buffer, which needs peer access from its device to devices[0].
  * Consecutive frames alternate between two sets of streams and buffers per rank, so a rank's next frame starts while the
- * exchange of its previous one is still in flight.  With stats == NULL, device pointers and CRT_OUT_DEVICE the call is
+ * exchange of its previous one is still in flight.  When every rank has a device of its own, each rank's part of a frame is
+ * enqueued by a worker thread of that rank (made at commit; CRT_MULTI_THREADS=0 / 1 forbids / forces), so the call costs the
+ * host one rank's enqueue time plus the exchange, not n ranks'.  With stats == NULL, device pointers and CRT_OUT_DEVICE the call is
  * asynchronous: the frame is complete for work enqueued afterwards on p->stream (a stream of devices[0]; NULL = its
  * default stream).  Otherwise the call returns when the frame is in out_rgb.  stats: sums over the ranks, kernel_ms =
  * the slowest rank's kernel. */

@@ -55,8 +55,9 @@ def _commit(scenes, capi, desc, devices):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks", [1, 2, 3, 8])
-def test_multi_tile_mode_is_bitwise_the_single_device_frame(oracle, capi, scenes, ranks):
+@pytest.mark.parametrize("ranks,threads", [(1, "1"), (2, "0"), (3, "1"), (8, "0"), (8, "1")])
+def test_multi_tile_mode_is_bitwise_the_single_device_frame(oracle, capi, scenes, monkeypatch, ranks, threads):
+    monkeypatch.setenv("CRT_MULTI_THREADS", threads)             # 1: every rank's part of a frame is enqueued by a thread of its own
     desc = scenes.cats()
     s = _commit(scenes, capi, desc, [0] * ranks)
     W, H, spp = 203, 117, 4                                      # ragged
@@ -81,9 +82,10 @@ def test_multi_tile_mode_is_bitwise_the_single_device_frame(oracle, capi, scenes
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ranks", [1, 2, 4])
-def test_multi_sample_mode_sums_rank_parts_in_rank_order(capi, scenes, ranks):
+@pytest.mark.parametrize("ranks,threads", [(1, "0"), (2, "1"), (4, "0"), (4, "1")])
+def test_multi_sample_mode_sums_rank_parts_in_rank_order(capi, scenes, monkeypatch, ranks, threads):
     import torch
+    monkeypatch.setenv("CRT_MULTI_THREADS", threads)
     desc = scenes.cats()
     s = _commit(scenes, capi, desc, [0] * ranks)
     W, H, spp = 160, 90, 8
