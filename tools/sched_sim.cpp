@@ -4,6 +4,10 @@
 //   policy 0: the shipped one (a shade phase when >= T lanes are not walking, else node / leaf steps by majority vote)
 //   policy 1: two contexts per lane (one walking, one parked: a fresh ray waiting for the lane, or a finished one waiting
 //             for the shade phase); lanes whose walk ends swap in their parked fresh ray at refill points
+//   policy 2: postponed leaves (speculative traversal, Aila & Laine 2009): a lane that reaches a leaf keeps the leaf in a one-entry
+//             slot and goes on with its node steps; leaf steps serve every lane that holds a leaf, and are voted for by the lanes
+//             that cannot go on without one.  (The trace is the unspeculated walk: the node steps that a later hit would have
+//             pruned are not added, so the figure is an upper bound of the gain.)
 // Build: g++ -O2 -std=c++17 tools/sched_sim.cpp -o /tmp/sched_sim ; run: /tmp/sched_sim trace.bin policy T [R]
 #include <algorithm>
 #include <cstdint>
@@ -22,6 +26,7 @@ static uint32_t SPP = 64, CHUNK = 2;
 // cost model (issue cycles per wave)
 static double C_A = 2130, C_VOTE = 45, C_NODE = 210, C_LEAF0 = 150, C_LEAFK = 130, C_SWAP = 150;
 static int STEPS_PER_VOTE = 4;
+static double C_ABSORB = 0; // policy 2: what keeping the postponed leaf adds to a node step (env SIM_ABSORB)
 static int PEEL = 0; // study: the walk's first node step (the root node) done by the shade phase, whose cost grows by C_PEEL
 static double C_PEEL = 110;
 
@@ -29,6 +34,7 @@ struct Ctx {
     int state = 0;               // 0 needs a unit, 1 ready for the shade phase (hit resolved / new sample), 2 walking, 3 fresh (a ray waiting to walk), 4 done
     uint32_t unit = 0, sample = 0, seg = 0, step = 0; // sample: index within the unit; seg: index within the sample; step: within the segment
     bool has_unit = false, started = false;
+    int pend = -1;               // policy 2: tests of the postponed leaf, -1 = none
 };
 struct Queue { uint64_t next = 0, total = 0; };
 
@@ -70,6 +76,8 @@ int main(int argc, char **argv)
     { uint8_t buf[1 << 16]; size_t n; while ((n = fread(buf, 1, sizeof buf, f)) > 0) raw.insert(raw.end(), buf, buf + n); }
     fclose(f);
     const int policy = atoi(argv[2]) % 10, T = atoi(argv[3]), R = argc > 4 ? atoi(argv[4]) : 8;
+    if (getenv("SIM_ABSORB")) C_ABSORB = atof(getenv("SIM_ABSORB"));
+    if (getenv("SIM_STEPS")) STEPS_PER_VOTE = atoi(getenv("SIM_STEPS"));
     PEEL = atoi(argv[2]) / 10; // policy 10: the shipped schedule with the root node's step peeled into the shade phase
     if (PEEL) C_A += C_PEEL;
     for (size_t i = 0; i < raw.size(); i++) {
@@ -131,6 +139,56 @@ int main(int argc, char **argv)
             w.t += C_A; sumA += C_A; nA++; lanesA += lanes;
         } else {
             // ---------------- walk phase: votes until enough lanes wait for the shade phase (or can refill)
+            if (policy == 2) {
+                for (;;) {
+                    // absorb: a lane at a leaf with an empty slot takes the leaf along
+                    int n_inner = 0, n_blocked = 0, n_pend = 0, nfin = 0;
+                    for (int l = 0; l < 64; l++) {
+                        Ctx &a = act(l);
+                        if (a.state == 2) {
+                            const Seg &sg = cur_seg(a);
+                            if (a.pend < 0 && a.step < sg.n && steps[sg.first + a.step] != 1) { a.pend = steps[sg.first + a.step] - 0x10; a.step++; }
+                            if (a.step == sg.n && a.pend < 0) a.state = 1;
+                        }
+                        if (a.state == 2) {
+                            const Seg &sg = cur_seg(a);
+                            const bool inner = a.step < sg.n && steps[sg.first + a.step] == 1;
+                            if (inner) n_inner++;
+                            if (a.pend >= 0) { n_pend++; if (!inner) n_blocked++; }
+                        }
+                        if (a.state == 0 || a.state == 1) nfin++;
+                    }
+                    if (n_inner + n_pend == 0 || nfin >= T) break;
+                    w.t += C_VOTE; sumV += C_VOTE;
+                    if (n_inner >= n_blocked && n_inner > 0) {
+                        for (int k = 0; k < STEPS_PER_VOTE; k++) {
+                            int lanes = 0;
+                            for (int l = 0; l < 64; l++) {
+                                Ctx &a = act(l);
+                                if (a.state != 2) continue;
+                                const Seg &sg = cur_seg(a);
+                                if (a.step >= sg.n || steps[sg.first + a.step] != 1) continue;
+                                lanes++;
+                                a.step++;
+                            }
+                            if (!lanes) break;
+                            w.t += C_NODE + C_ABSORB; sumN += C_NODE + C_ABSORB; nN++; lanesN += lanes;
+                        }
+                    } else {
+                        int lanes = 0, maxk = 0;
+                        for (int l = 0; l < 64; l++) {
+                            Ctx &a = act(l);
+                            if (a.state != 2 || a.pend < 0) continue;
+                            lanes++; maxk = std::max(maxk, a.pend);
+                            a.pend = -1;
+                        }
+                        const double cst = C_LEAF0 + C_LEAFK * maxk;
+                        w.t += cst; sumL += cst; nL++; lanesL += lanes;
+                    }
+                }
+                pq.push({ w.t, wi });
+                continue;
+            }
             for (;;) {
                 int n_inner = 0, n_leaf = 0, nfin = 0, nref = 0;
                 for (int l = 0; l < 64; l++) {
