@@ -16,6 +16,7 @@ CRT_OK, CRT_ERR_INVALID, CRT_ERR_IO, CRT_ERR_HIP, CRT_ERR_LIMIT, CRT_ERR_NO_DEVI
 TEX_SOLID, TEX_CHECKER = 0, 1
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIFFUSE_LIGHT, MAT_DIELECTRIC = 0, 1, 2, 3
 BUILD_GPU_LBVH = 1
+BUILD_GPU_SAH = 2
 OUT_ACCUM, OUT_COMPACT, COUNT_WORK, OUT_DEVICE = 1, 2, 4, 8
 MULTI_TILE, MULTI_SAMPLE = 0, 1
 NOALLOC_SLAB_BYTES = 32 << 20
@@ -59,7 +60,7 @@ class SceneInfo(C.Structure):  # crt_scene_info
                 ("num_nodes", C.c_uint32), ("bvh_depth", C.c_uint32), ("max_leaf_size", C.c_uint32), ("device", C.c_uint32),
                 ("node_bytes", C.c_uint64), ("triangle_bytes", C.c_uint64), ("sphere_bytes", C.c_uint64),
                 ("bounds_min", C.c_float * 3), ("bounds_max", C.c_float * 3), ("builder", C.c_uint32), ("build_ms", C.c_float),
-                ("node_width", C.c_uint32), ("binary_depth", C.c_uint32)]
+                ("node_width", C.c_uint32), ("binary_depth", C.c_uint32), ("sah_cost", C.c_float)]
 
 
 # every symbol include/crt.h declares (tests check that the library exports exactly these)

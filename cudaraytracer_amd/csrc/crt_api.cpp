@@ -410,7 +410,7 @@ struct crt_scene {
     FlatBvh bvh;
     std::vector<Shade> shades; // materials joined with their textures (device record)
     std::vector<q4> normals;   // per triangle slot: unit normal + primitive id (crt_traverse.h: triangle_normal)
-    uint32_t builder = 0, binary_depth = 0; float build_ms = 0.0f;
+    uint32_t builder = 0, binary_depth = 0; float build_ms = 0.0f, sah_cost = 0.0f;
     std::vector<Sphere> flat_spheres; // the spheres that are tested before the walk (the others are slots of the tree)
     bool sphere_slots = false;        // some spheres went into the tree
     Tuning tuning;
@@ -520,7 +520,7 @@ static int upload(void **dst, const std::vector<T> &v)
 
 // GPU builder (crt_lbvh.hip): ranks + LBVH on the device.  Returns false (with everything untouched) when the scene or the
 // resulting tree does not qualify, so that the caller falls back to the host path.
-static bool commit_gpu_lbvh(crt_scene *s, int device, uint32_t max_leaf)
+static bool commit_gpu_lbvh(crt_scene *s, int device, uint32_t max_leaf, uint32_t tree_kind)
 {
     if (device < 0 || s->tris.empty() || s->spheres.size() > 8 || s->tris.size() >= (1u << 28)) return false;
     int ndev = 0;
@@ -547,7 +547,7 @@ static bool commit_gpu_lbvh(crt_scene *s, int device, uint32_t max_leaf)
         }
     }
     LbvhOutput out;
-    if (lbvh_build(tri9.data(), mat.data(), (uint32_t)n, su, !sph.empty(), sph.data(), (uint32_t)sph.size(), max_leaf, out, nullptr) != hipSuccess) {
+    if (lbvh_build(tri9.data(), mat.data(), (uint32_t)n, su, !sph.empty(), sph.data(), (uint32_t)sph.size(), max_leaf, tree_kind, out, nullptr) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
@@ -567,14 +567,14 @@ static bool commit_gpu_lbvh(crt_scene *s, int device, uint32_t max_leaf)
     s->bvh.nodes.swap(out.nodes);
     s->bvh.tris.swap(out.slots);
     s->bvh.root_ref = out.root_ref; s->bvh.root_box = out.root_box; s->bvh.depth = out.depth; s->bvh.max_leaf = max_leaf;
-    s->builder = 1; s->build_ms = out.build_ms;
+    s->builder = tree_kind == LBVH_TREE_SAH ? 2u : 1u; s->build_ms = out.build_ms;
     return true;
 }
 
 extern "C" int crt_scene_commit(crt_scene *s, int device)
 {
     const char *b = getenv("CRT_BUILDER");
-    return crt_scene_commit_ex(s, device, (b && strcmp(b, "lbvh") == 0) ? (uint32_t)CRT_BUILD_GPU_LBVH : 0u);
+    return crt_scene_commit_ex(s, device, (b && strcmp(b, "lbvh") == 0) ? (uint32_t)CRT_BUILD_GPU_LBVH : (b && strcmp(b, "gpusah") == 0) ? (uint32_t)CRT_BUILD_GPU_SAH : 0u);
 }
 
 // Host side of a commit: ranks, tree, shading records, normals (with CRT_BUILD_GPU_LBVH ranks and tree come from
@@ -588,7 +588,8 @@ static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
 
     const uint32_t max_leaf = (uint32_t)get_env_int("CRT_MAX_LEAF", 2);
     s->builder = 0; s->build_ms = 0.0f;
-    const bool gpu_built = (flags & CRT_BUILD_GPU_LBVH) && commit_gpu_lbvh(s, build_device, std::min(std::max(max_leaf, 1u), 8u));
+    const bool gpu_built = (flags & (CRT_BUILD_GPU_LBVH | CRT_BUILD_GPU_SAH)) &&
+                           commit_gpu_lbvh(s, build_device, std::min(std::max(max_leaf, 1u), 8u), (flags & CRT_BUILD_GPU_SAH) ? LBVH_TREE_SAH : LBVH_TREE_KARRAS);
     const auto host_t0 = std::chrono::steady_clock::now();
     if (!gpu_built) {
         // reference order: all triangles, then all spheres (scene.h:161-165)
@@ -639,6 +640,7 @@ static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
     // the default (DESIGN.md section 4 has the measurement).  The kernels for this format have the 16-level stack
     // (crt_kernels.hip: launch_wide); a tree that stays deeper than that keeps two children.
     s->binary_depth = s->bvh.depth;
+    s->sah_cost = bvh_sah_cost(s->bvh);
     if (s->tuning.bvh_wide == 1) {
         FlatBvh wide = s->bvh;
         widen_bvh(wide);
@@ -750,7 +752,7 @@ extern "C" int crt_scene_get_info(const crt_scene *s, crt_scene_info *info)
     info->node_bytes = s->bvh.nodes.size() * sizeof(q4); info->triangle_bytes = s->bvh.tris.size() * sizeof(q4);
     info->sphere_bytes = s->flat_spheres.size() * sizeof(Sphere);
     info->bounds_min[0] = s->bvh.root_box.mn.x; info->bounds_min[1] = s->bvh.root_box.mn.y; info->bounds_min[2] = s->bvh.root_box.mn.z;
-    info->builder = s->builder; info->build_ms = s->build_ms; info->node_width = s->bvh.wide ? 4u : 2u; info->binary_depth = s->binary_depth;
+    info->builder = s->builder; info->build_ms = s->build_ms; info->node_width = s->bvh.wide ? 4u : 2u; info->binary_depth = s->binary_depth; info->sah_cost = s->sah_cost;
     info->bounds_max[0] = s->bvh.root_box.mx.x; info->bounds_max[1] = s->bvh.root_box.mx.y; info->bounds_max[2] = s->bvh.root_box.mx.z;
     return CRT_OK;
 }

@@ -296,6 +296,33 @@ void renumber_breadth_first(std::vector<q4> &nodes_io, int &root_ref)
     root_ref = 0;
 }
 
+float bvh_sah_cost(const FlatBvh &bvh)
+{
+    if (bvh.wide || bvh.root_ref < 0 || bvh.root_ref == CRT_BVH_NONE) return 0.0f;
+    auto area = [](const q4 &mn, const q4 &mx) {
+        const double dx = (double)mx.x - mn.x, dy = (double)mx.y - mn.y, dz = (double)mx.z - mn.z;
+        return dx * dy + dy * dz + dz * dx;
+    };
+    q4 rmn, rmx;
+    rmn.x = bvh.root_box.mn.x; rmn.y = bvh.root_box.mn.y; rmn.z = bvh.root_box.mn.z; rmx.x = bvh.root_box.mx.x; rmx.y = bvh.root_box.mx.y; rmx.z = bvh.root_box.mx.z;
+    rmn.w = rmx.w = 0.0f;
+    const double root_area = area(rmn, rmx);
+    if (!(root_area > 0)) return 0.0f;
+    double cost = root_area; // the root's own visit
+    const size_t n = bvh.nodes.size() / 4;
+    for (size_t i = 0; i < n; i++) {
+        const q4 *q = &bvh.nodes[4 * i];
+        for (int k = 0; k < 2; k++) {
+            int ref;
+            std::memcpy(&ref, &q[k].w, 4);
+            const double a = area(q[2 * k], q[2 * k + 1]);
+            if (ref >= 0) cost += a;
+            else if (ref != CRT_BVH_NONE) cost += 1.3 * (double)(((~ref) & 7) + 1) * a;
+        }
+    }
+    return (float)(cost / root_area);
+}
+
 void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t> &rank, const std::vector<BvhSphere> &spheres, uint32_t max_leaf,
                FlatBvh &out)
 {

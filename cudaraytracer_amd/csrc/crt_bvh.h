@@ -51,6 +51,10 @@ void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t
 // Two-child tree -> four-child tree of 128-byte nodes (crt_traverse.h), breadth first; depth becomes the wide tree's.
 void widen_bvh(FlatBvh &bvh);
 
+// Surface-area cost of a two-child tree: 1 per node visited + 1.3 per triangle tested, each weighted by the area of its box
+// over the root box's (the builders' own objective; lower = fewer expected steps per ray).  0 for a tree without nodes.
+float bvh_sah_cost(const FlatBvh &bvh);
+
 // Breadth-first renumbering of a flattened tree (drops unreachable records): what "the first N nodes" means to the kernels.
 void renumber_breadth_first(std::vector<q4> &nodes, int &root_ref);
 

@@ -13,7 +13,7 @@ struct LbvhSphereCodes { uint32_t count; uint32_t code[8]; }; // Morton codes of
 struct LbvhSphereInput { Box refbox; };                       // reference box of a sphere (sphere.h:12-15)
 
 struct LbvhOutput {
-    std::vector<q4> nodes;              // 4 per node, Karras numbering (records of collapsed sub-trees are zero)
+    std::vector<q4> nodes;              // 4 per node, Karras numbering / allocation order (records of collapsed sub-trees are zero)
     std::vector<q4> slots;              // 3 per triangle, in sorted (rank) order
     std::vector<uint32_t> rank_of_tri;  // global rank of triangle i
     std::vector<uint32_t> sorted_codes; // the triangles' codes in sorted order (for the spheres' ranks)
@@ -27,9 +27,20 @@ struct LbvhOutput {
 // bvh.h:24-48 on the host, for the spheres (defined in crt_bvh.cpp next to the code it shares with reference_ranks)
 uint32_t lbvh_host_morton(const Box &refbox, const Box &scene);
 
+// The tree over the sorted triangles: Karras LBVH (crt_lbvh.hip) or binned SAH by levels (crt_gsah.hip)
+enum { LBVH_TREE_KARRAS = 0, LBVH_TREE_SAH = 1 };
+
+// crt_gsah.hip: binned-SAH tree over n triangles on the device.  d_refbox6: the reference boxes (6 floats each, min xyz max
+// xyz); d_order: a starting order of the triangles (any permutation; Morton order makes the rare median splits spatial);
+// tri_box: union of the reference boxes.  Writes the node records (room for n + 1: record n receives the root's box and
+// reference) and the 48-byte slots in leaf order.
+struct GsahResult { uint32_t num_records = 0, depth = 0, levels_run = 0, small_nodes = 0; int root_ref = CRT_BVH_NONE; Box root_box{}; };
+hipError_t gsah_build(const float *d_tri9, const int *d_mat, const float *d_refbox6, const uint32_t *d_order, const uint32_t *d_rank_of_tri, uint32_t n,
+                      float margin, const float tri_box[6], uint32_t max_leaf, float tri_cost, q4 *d_records, q4 *d_slots, GsahResult &res, hipStream_t stream);
+
 // h_tri9: 9 floats per triangle (a, b, c); h_mat: material per triangle.  sphere_union: union of the spheres' reference
 // boxes (have_spheres false: none).  At most 8 spheres.  The device is the current one.
 hipError_t lbvh_build(const float *h_tri9, const int *h_mat, uint32_t n, const Box &sphere_union, bool have_spheres, const LbvhSphereInput *spheres,
-                      uint32_t nspheres, uint32_t max_leaf, LbvhOutput &out, hipStream_t stream);
+                      uint32_t nspheres, uint32_t max_leaf, uint32_t tree_kind, LbvhOutput &out, hipStream_t stream);
 
 } // namespace crt

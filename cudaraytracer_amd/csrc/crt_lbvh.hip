@@ -14,6 +14,7 @@
 // rocprim::radix_sort_pairs is a stable LSD radix sort like thrust::sort_by_key (scene.h:301).
 #include <hip/hip_runtime.h>
 #include <cfloat>
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(256) void depth_kernel(int n, uint32_t max_leaf, co
 } // namespace
 
 hipError_t lbvh_build(const float *h_tri9, const int *h_mat, uint32_t n, const Box &sphere_union, bool have_spheres, const LbvhSphereInput *spheres,
-                      uint32_t nspheres, uint32_t max_leaf, LbvhOutput &out, hipStream_t stream)
+                      uint32_t nspheres, uint32_t max_leaf, uint32_t tree_kind, LbvhOutput &out, hipStream_t stream)
 {
     float *d_tri9 = nullptr; int *d_mat = nullptr; Box6 *d_refbox = nullptr, *d_leafbox = nullptr, *d_nodebox = nullptr;
     uint32_t *d_red = nullptr, *d_code = nullptr, *d_idx = nullptr, *d_code_s = nullptr, *d_idx_s = nullptr;
@@ -306,7 +307,7 @@ hipError_t lbvh_build(const float *h_tri9, const int *h_mat, uint32_t n, const B
     LBVH_TRY(hipMalloc((void **)&d_depth, sizeof(uint32_t)));
     LBVH_TRY(hipMalloc((void **)&d_code64, (size_t)n * sizeof(unsigned long long)));
     LBVH_TRY(hipMalloc((void **)&d_code64_s, (size_t)n * sizeof(unsigned long long)));
-    LBVH_TRY(hipMalloc((void **)&d_nodes, (size_t)nint * 4 * sizeof(q4)));
+    LBVH_TRY(hipMalloc((void **)&d_nodes, ((size_t)n + 1) * 4 * sizeof(q4))); // (the SAH builder: n - 1 records + the one above the root)
     LBVH_TRY(hipMalloc((void **)&d_slots, (size_t)n * 3 * sizeof(q4)));
     LBVH_TRY(hipEventCreate(&e0));
     LBVH_TRY(hipEventCreate(&e1));
@@ -367,19 +368,27 @@ hipError_t lbvh_build(const float *h_tri9, const int *h_mat, uint32_t n, const B
         LBVH_TRY(hipMalloc(&d_temp64, temp64_bytes ? temp64_bytes : 16));
         LBVH_TRY(rocprim::radix_sort_pairs(d_temp64, temp64_bytes, d_code64, d_code64_s, d_idx, d_idx_s, (size_t)n, 0u, 63u, stream));
     }
-    if (n > 1) {
-        hipLaunchKernelGGL(hierarchy_kernel, dim3((n - 1 + 255u) / 256u), dim3(256), 0, stream, d_code64_s, (int)n, d_child0, d_child1, d_first, d_last, d_pnode, d_pleaf);
+    GsahResult sah;
+    if (tree_kind == LBVH_TREE_SAH) {
+        const float tri_box[6] = { ord2f(red[0]), ord2f(red[1]), ord2f(red[2]), ord2f(red[3]), ord2f(red[4]), ord2f(red[5]) };
+        float tri_cost = 1.3f; // crt_bvh.cpp: Builder::TRI_COST
+        if (const char *e = getenv("CRT_SAH_TRI_COST")) tri_cost = (float)atof(e);
+        LBVH_TRY(gsah_build(d_tri9, d_mat, (const float *)d_refbox, d_idx_s, d_rank, n, margin, tri_box, max_leaf, tri_cost, d_nodes, d_slots, sah, stream));
+    } else {
+        if (n > 1) {
+            hipLaunchKernelGGL(hierarchy_kernel, dim3((n - 1 + 255u) / 256u), dim3(256), 0, stream, d_code64_s, (int)n, d_child0, d_child1, d_first, d_last, d_pnode, d_pleaf);
+            LBVH_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(fit_kernel, dim3(blocks), dim3(256), 0, stream, d_tri9, d_mat, d_refbox, d_idx_s, (int)n, margin, d_child0, d_child1,
+                           d_pnode, d_pleaf, d_leafbox, d_nodebox, d_flags, d_slots, d_rank);
         LBVH_TRY(hipGetLastError());
-    }
-    hipLaunchKernelGGL(fit_kernel, dim3(blocks), dim3(256), 0, stream, d_tri9, d_mat, d_refbox, d_idx_s, (int)n, margin, d_child0, d_child1,
-                       d_pnode, d_pleaf, d_leafbox, d_nodebox, d_flags, d_slots, d_rank);
-    LBVH_TRY(hipGetLastError());
-    if (n > 1) {
-        hipLaunchKernelGGL(emit_kernel, dim3((n - 1 + 255u) / 256u), dim3(256), 0, stream, (int)n, max_leaf, d_child0, d_child1, d_first, d_last, d_leafbox,
-                           d_nodebox, d_nodes);
-        LBVH_TRY(hipGetLastError());
-        hipLaunchKernelGGL(depth_kernel, dim3(blocks), dim3(256), 0, stream, (int)n, max_leaf, d_first, d_last, d_pnode, d_pleaf, d_depth);
-        LBVH_TRY(hipGetLastError());
+        if (n > 1) {
+            hipLaunchKernelGGL(emit_kernel, dim3((n - 1 + 255u) / 256u), dim3(256), 0, stream, (int)n, max_leaf, d_child0, d_child1, d_first, d_last, d_leafbox,
+                               d_nodebox, d_nodes);
+            LBVH_TRY(hipGetLastError());
+            hipLaunchKernelGGL(depth_kernel, dim3(blocks), dim3(256), 0, stream, (int)n, max_leaf, d_first, d_last, d_pnode, d_pleaf, d_depth);
+            LBVH_TRY(hipGetLastError());
+        }
     }
     LBVH_TRY(hipEventRecord(e1, stream));
 
@@ -390,22 +399,31 @@ hipError_t lbvh_build(const float *h_tri9, const int *h_mat, uint32_t n, const B
     out.slots.resize((size_t)n * 3);
     LBVH_TRY(hipMemcpyAsync(out.rank_of_tri.data(), d_rank, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     LBVH_TRY(hipMemcpyAsync(out.slots.data(), d_slots, (size_t)n * 3 * sizeof(q4), hipMemcpyDeviceToHost, stream));
-    Box6 rootbox;
+    Box6 rootbox{};
     uint32_t depth = 0;
-    if (n > max_leaf) {
-        out.nodes.resize((size_t)(n - 1) * 4);
-        LBVH_TRY(hipMemcpyAsync(out.nodes.data(), d_nodes, (size_t)(n - 1) * 4 * sizeof(q4), hipMemcpyDeviceToHost, stream));
-        out.root_ref = 0;
+    if (tree_kind == LBVH_TREE_SAH) {
+        out.nodes.resize((size_t)sah.num_records * 4);
+        if (sah.num_records) LBVH_TRY(hipMemcpyAsync(out.nodes.data(), d_nodes, (size_t)sah.num_records * 4 * sizeof(q4), hipMemcpyDeviceToHost, stream));
+        out.root_ref = sah.root_ref;
+        LBVH_TRY(hipStreamSynchronize(stream));
+        out.root_box = sah.root_box;
+        out.depth = sah.depth;
     } else {
-        out.nodes.clear();
-        out.root_ref = ~(int)((0u << 3) | (n - 1u));
+        if (n > max_leaf) {
+            out.nodes.resize((size_t)(n - 1) * 4);
+            LBVH_TRY(hipMemcpyAsync(out.nodes.data(), d_nodes, (size_t)(n - 1) * 4 * sizeof(q4), hipMemcpyDeviceToHost, stream));
+            out.root_ref = 0;
+        } else {
+            out.nodes.clear();
+            out.root_ref = ~(int)((0u << 3) | (n - 1u));
+        }
+        LBVH_TRY(hipMemcpyAsync(&rootbox, n > 1 ? (const void *)d_nodebox : (const void *)d_leafbox, sizeof rootbox, hipMemcpyDeviceToHost, stream));
+        LBVH_TRY(hipMemcpyAsync(&depth, d_depth, sizeof depth, hipMemcpyDeviceToHost, stream));
+        LBVH_TRY(hipStreamSynchronize(stream));
+        out.root_box.mn = mk3(rootbox.mnx, rootbox.mny, rootbox.mnz);
+        out.root_box.mx = mk3(rootbox.mxx, rootbox.mxy, rootbox.mxz);
+        out.depth = depth;
     }
-    LBVH_TRY(hipMemcpyAsync(&rootbox, n > 1 ? (const void *)d_nodebox : (const void *)d_leafbox, sizeof rootbox, hipMemcpyDeviceToHost, stream));
-    LBVH_TRY(hipMemcpyAsync(&depth, d_depth, sizeof depth, hipMemcpyDeviceToHost, stream));
-    LBVH_TRY(hipStreamSynchronize(stream));
-    out.root_box.mn = mk3(rootbox.mnx, rootbox.mny, rootbox.mnz);
-    out.root_box.mx = mk3(rootbox.mxx, rootbox.mxy, rootbox.mxz);
-    out.depth = depth;
     float ms = 0.0f;
     LBVH_TRY(hipEventElapsedTime(&ms, e0, e1));
     out.build_ms = ms;

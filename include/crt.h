@@ -92,7 +92,13 @@ int crt_scene_commit(crt_scene *s, int device);
  * than the host's SAH tree, the rendered result is the same.  Needs a device, triangles and at most 8 spheres; falls
  * back to the host builder otherwise (crt_scene_info.builder tells).  crt_scene_commit(s, d) = commit_ex(s, d, 0), or
  * CRT_BUILD_GPU_LBVH when the environment has CRT_BUILDER=lbvh. */
-enum { CRT_BUILD_GPU_LBVH = 1u };
+enum { CRT_BUILD_GPU_LBVH = 1u,
+/* CRT_BUILD_GPU_SAH (round 3; same reference loop, bvh.h:91-185): the ranks as above, and the tree by the host builder's own
+ * algorithm run on the device -- 16 centroid bins per axis, area x count, leaves where a split does not pay -- level by level
+ * for nodes of more than 64 triangles and one wave per smaller node (crt_gsah.hip).  The host tree's quality (same SAH cost
+ * within a percent, crt_scene_info.sah_cost) in tens of milliseconds instead of seconds for a million triangles.
+ * CRT_BUILDER=gpusah selects it for crt_scene_commit.  Same conditions and fall-back as CRT_BUILD_GPU_LBVH. */
+       CRT_BUILD_GPU_SAH = 2u };
 int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags);
 /* Multi-GPU, one process driving n HIP devices (new: the reference is single-GPU, renderer.h:64-73 / kernel.cu:77-88;
  * BASELINE.json asks for tile / sample partitioning over the 8 GPUs of a node).  Like crt_scene_commit_ex, then the scene
@@ -116,10 +122,11 @@ typedef struct crt_scene_info {
     uint32_t device;         /* UINT32_MAX when prepared with CRT_DEVICE_NONE */
     uint64_t node_bytes, triangle_bytes, sphere_bytes; /* resident HBM footprint */
     float bounds_min[3], bounds_max[3];                /* triangle BVH root box  */
-    uint32_t builder;        /* 0 = host SAH, 1 = GPU LBVH                                                  */
+    uint32_t builder;        /* 0 = host SAH, 1 = GPU LBVH, 2 = GPU SAH                                      */
     float build_ms;          /* GPU LBVH: hipEvent time of the build kernels and the sort; host SAH: wall time */
     uint32_t node_width;     /* 2; 4 when the scene was committed with CRT_BVH_WIDE=1 in the environment (four-child nodes: an option, slower) */
     uint32_t binary_depth;   /* depth of the two-child tree the builder made (= bvh_depth when node_width is 2)                          */
+    float sah_cost;          /* surface-area cost of the two-child tree: expected node visits + 1.3 x triangle tests of a ray that hits the root box */
 } crt_scene_info;
 int crt_scene_get_info(const crt_scene *s, crt_scene_info *info);
 /* rank[i] = position of primitive i (triangles first, then spheres) in the reference's sorted Morton order
