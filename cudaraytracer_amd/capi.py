@@ -17,6 +17,7 @@ TEX_SOLID, TEX_CHECKER = 0, 1
 MAT_LAMBERTIAN, MAT_METAL, MAT_DIFFUSE_LIGHT, MAT_DIELECTRIC = 0, 1, 2, 3
 BUILD_GPU_LBVH = 1
 BUILD_GPU_SAH = 2
+BUILD_AUTO = 4
 OUT_ACCUM, OUT_COMPACT, COUNT_WORK, OUT_DEVICE = 1, 2, 4, 8
 MULTI_TILE, MULTI_SAMPLE = 0, 1
 NOALLOC_SLAB_BYTES = 32 << 20

@@ -50,7 +50,7 @@ public:
             return;
         }
         if ((*d_world)->devices != devices) {
-            checkCrtErrors(crt_scene_commit_devices((*d_world)->scene, devices.data(), (uint32_t)devices.size(), 0));
+            checkCrtErrors(crt_scene_commit_devices((*d_world)->scene, devices.data(), (uint32_t)devices.size(), CRT_BUILD_AUTO));
             (*d_world)->devices = devices;
         }
         checkCrtErrors(crt_render_multi((*d_world)->scene, &cam, &p, multi_mode, &framebuffer[0].x, nullptr, &last_stats));

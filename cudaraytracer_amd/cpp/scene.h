@@ -110,7 +110,7 @@ private:
     {
         if (devices.empty()) checkCrtErrors(crt_scene_commit(world->scene, device));
         else {
-            checkCrtErrors(crt_scene_commit_devices(world->scene, devices.data(), (uint32_t)devices.size(), 0));
+            checkCrtErrors(crt_scene_commit_devices(world->scene, devices.data(), (uint32_t)devices.size(), CRT_BUILD_AUTO));
             world->devices = devices;
         }
     }

@@ -90,15 +90,18 @@ int crt_scene_commit(crt_scene *s, int device);
  * thrust::sort_by_key + build_bvh<<<1,1>>>, bvh.h:13-185, scene.h:288-307): boxes, Morton codes, the stable radix sort
  * (= the ranks) and a Karras LBVH over that order are computed on the device in milliseconds; the tree traverses slower
  * than the host's SAH tree, the rendered result is the same.  Needs a device, triangles and at most 8 spheres; falls
- * back to the host builder otherwise (crt_scene_info.builder tells).  crt_scene_commit(s, d) = commit_ex(s, d, 0), or
- * CRT_BUILD_GPU_LBVH when the environment has CRT_BUILDER=lbvh. */
+ * back to the host builder otherwise (crt_scene_info.builder tells). */
 enum { CRT_BUILD_GPU_LBVH = 1u,
 /* CRT_BUILD_GPU_SAH (round 3; same reference loop, bvh.h:91-185): the ranks as above, and the tree by the host builder's own
  * algorithm run on the device -- 16 centroid bins per axis, area x count, leaves where a split does not pay -- level by level
  * for nodes of more than 64 triangles and one wave per smaller node (crt_gsah.hip).  The host tree's quality (same SAH cost
  * within a percent, crt_scene_info.sah_cost) in tens of milliseconds instead of seconds for a million triangles.
  * CRT_BUILDER=gpusah selects it for crt_scene_commit.  Same conditions and fall-back as CRT_BUILD_GPU_LBVH. */
-       CRT_BUILD_GPU_SAH = 2u };
+       CRT_BUILD_GPU_SAH = 2u,
+/* CRT_BUILD_AUTO: the library chooses -- the device's SAH builder for scenes of at least 32768 triangles (where the host takes
+ * longer than the device), the host's otherwise; both give the same tree quality.  This is what crt_scene_commit(s, d) passes
+ * unless the environment says CRT_BUILDER=host | gpusah | lbvh.  flags = 0 stays "host", as before. */
+       CRT_BUILD_AUTO = 4u };
 int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags);
 /* Multi-GPU, one process driving n HIP devices (new: the reference is single-GPU, renderer.h:64-73 / kernel.cu:77-88;
  * BASELINE.json asks for tile / sample partitioning over the 8 GPUs of a node).  Like crt_scene_commit_ex, then the scene

@@ -339,10 +339,10 @@ def test_gpu_lbvh_builder_same_ranks_same_image(oracle, capi, scenes, name):
 
 def test_gpu_lbvh_builder_on_the_1m_triangle_scene(capi, scenes, node_cache):
     desc = scenes.cat_grid()
-    host = scenes.build(desc, 0)
+    host = scenes.build(desc, 0, 0)
     gpu = scenes.build(desc, 0, capi.BUILD_GPU_LBVH)
     ig = gpu.info()
-    assert ig.builder == 1 and ig.num_triangles == 999912 and ig.bvh_depth <= 32
+    assert host.info().builder == 0 and ig.builder == 1 and ig.num_triangles == 999912 and ig.bvh_depth <= 32
     assert np.array_equal(host.ranks(), gpu.ranks())
     print("build: host SAH %.0f ms, GPU LBVH %.2f ms (depth %d vs %d)" % (host.info().build_ms, ig.build_ms, host.info().bvh_depth, ig.bvh_depth))
     assert ig.build_ms < 100.0
@@ -350,6 +350,101 @@ def test_gpu_lbvh_builder_on_the_1m_triangle_scene(capi, scenes, node_cache):
     rgb_h, ids_h, st_h = host.render(cam, 480, 270, 2, want_ids=True)
     rgb_g, ids_g, st_g = gpu.render(cam, 480, 270, 2, want_ids=True)
     assert np.array_equal(ids_g, ids_h) and np.array_equal(rgb_g, rgb_h) and st_g.rays == st_h.rays
+
+
+@pytest.mark.parametrize("name", ["cat", "cats"])
+def test_gpu_sah_builder_same_ranks_same_image_same_cost(oracle, capi, scenes, name):
+    """Row N1, second builder (crt_gsah.hip): the host builder's binned SAH run on the device.  Ranks are the host's, the frame
+    is the oracle's bit for bit, and the tree is as good as the host's by the builders' own measure (surface-area cost)."""
+    desc = getattr(scenes, name)()
+    host = scenes.build(desc, 0, 0)
+    gpu = scenes.build(desc, 0, capi.BUILD_GPU_SAH)
+    ih, ig = host.info(), gpu.info()
+    assert (ih.builder, ig.builder) == (0, 2) and ig.num_triangles == ih.num_triangles and 0 < ig.bvh_depth <= 32
+    assert np.array_equal(host.ranks(), gpu.ranks())
+    assert np.allclose(np.array(ig.bounds_min), np.array(ih.bounds_min)) and np.allclose(np.array(ig.bounds_max), np.array(ih.bounds_max))
+    assert 0 < ig.sah_cost <= 1.02 * ih.sah_cost and abs(int(ig.num_nodes) - int(ih.num_nodes)) <= 0.05 * ih.num_nodes
+    width, height, spp = 320, 180, 4
+    params, cam = scenes.make_camera(width)
+    rgb_h, ids_h, st_h = host.render(cam, width, height, spp, want_ids=True)
+    rgb_g, ids_g, st_g = gpu.render(cam, width, height, spp, want_ids=True)
+    assert np.array_equal(ids_g, ids_h) and np.array_equal(rgb_g, rgb_h) and st_g.rays == st_h.rays
+    fb, rids, _, rst = oracle.RefScene(desc).render(oracle.make_camera(params, width), width, height, spp)
+    assert np.array_equal(ids_g, rids) and np.array_equal(rgb_g.reshape(fb.shape), fb) and st_g.rays == rst.rays
+
+
+def test_gpu_sah_builder_on_the_1m_triangle_scene(capi, scenes, node_cache):
+    """999,912 triangles: twenty levels of grid-wide kernels, then ~30 k small nodes finished by one wave each.  The tree must
+    cost what the host's costs (within 5 % of the SAH tree's frame rate, built in <= 30 ms), and
+    crt_scene_commit picks this builder on its own for a scene of this size."""
+    desc = scenes.cat_grid()
+    host = scenes.build(desc, 0, 0)
+    gpu = scenes.build(desc, 0, capi.BUILD_GPU_SAH)
+    gpu = scenes.build(desc, 0, capi.BUILD_GPU_SAH)  # (the first build in a process also loads the code object)
+    auto = scenes.build(desc, 0)
+    ih, ig = host.info(), gpu.info()
+    assert (ih.builder, ig.builder, auto.info().builder) == (0, 2, 2) and ig.num_triangles == 999912 and ig.bvh_depth <= 32
+    assert np.array_equal(host.ranks(), gpu.ranks())
+    print("build: host SAH %.0f ms (cost %.3f, depth %d), GPU SAH %.2f ms (cost %.3f, depth %d)" % (ih.build_ms, ih.sah_cost, ih.bvh_depth, ig.build_ms, ig.sah_cost, ig.bvh_depth))
+    assert ig.build_ms < 30.0 and ig.sah_cost <= 1.02 * ih.sah_cost
+    _, cam = scenes.make_camera(480, **scenes.GRID_CAMERA)
+    rgb_h, ids_h, st_h = host.render(cam, 480, 270, 2, want_ids=True)
+    rgb_g, ids_g, st_g = gpu.render(cam, 480, 270, 2, want_ids=True, flags=capi.COUNT_WORK)
+    st_hw = host.render(cam, 480, 270, 2, flags=capi.COUNT_WORK)[2]
+    assert np.array_equal(ids_g, ids_h) and np.array_equal(rgb_g, rgb_h) and st_g.rays == st_h.rays
+    assert st_g.nodes <= 1.03 * st_hw.nodes and st_g.tri_tests <= 1.03 * st_hw.tri_tests
+
+
+def _sliver_scene(scenes, capi, n):
+    """n nested, strongly overlapping slivers (tests/test_host.py: test_depth_bound_on_degenerate_input): SAH alone would build a
+    chain; the depth bound has to force object medians."""
+    d = scenes._base()
+    d["materials"].append(dict(type=capi.MAT_LAMBERTIAN, rgb=(0.7, 0.3, 0.16), param=0.0, texture=None))
+    scenes._add_ref_spheres(d)
+    k = np.arange(n, dtype=np.float32)
+    v = np.zeros((3 * n, 3), np.float32)
+    v[0::3] = np.stack([0 * k - 1.0, 0 * k + 0.2, 0 * k], 1)
+    v[1::3] = np.stack([1.0001 ** k - 1.0, 0 * k + 0.2, 0 * k], 1)
+    v[2::3] = np.stack([0 * k - 1.0, 1.0001 ** k + 0.2, 1e-3 * k], 1)
+    d["meshes"].append(dict(vertices=v, indices=np.arange(3 * n, dtype=np.uint32).reshape(n, 3), material=0))
+    return d
+
+
+@pytest.mark.parametrize("n", [2, 9, 63, 64, 65, 129, 1000])
+def test_gpu_sah_builder_sizes_around_one_wave(oracle, scenes, capi, n):
+    """Trees on both sides of the 64 triangles that one wave finishes on its own (n <= 64: no level kernels at all; 65: one level
+    and two small nodes), against the oracle."""
+    desc = scenes.terrain(2)
+    me = desc["meshes"][0]
+    rng = np.random.default_rng(n)
+    c = rng.uniform(-1.5, 1.5, size=(n, 1, 3)).astype(np.float32) * np.array([1.0, 0.3, 1.0], np.float32) + np.array([0.0, 1.0, 0.0], np.float32)
+    v = (c + rng.uniform(-0.4, 0.4, size=(n, 3, 3)).astype(np.float32)).reshape(3 * n, 3)
+    desc["meshes"] = [dict(vertices=v, indices=np.arange(3 * n, dtype=np.uint32).reshape(n, 3), material=me["material"])]
+    s = scenes.build(desc, 0, capi.BUILD_GPU_SAH)
+    host = scenes.build(desc, 0, 0)
+    assert s.info().builder == 2 and s.info().bvh_depth <= 32 and s.info().sah_cost <= 1.05 * host.info().sah_cost + 1e-6
+    assert np.array_equal(s.ranks(), host.ranks())
+    width, height, spp = 128, 72, 2
+    params, cam = scenes.make_camera(width)
+    rgb, ids, st = s.render(cam, width, height, spp, want_ids=True)
+    fb, rids, _, rst = oracle.RefScene(desc).render(oracle.make_camera(params, width), width, height, spp)
+    assert np.array_equal(ids, rids) and np.array_equal(rgb.reshape(fb.shape), fb) and st.rays == rst.rays
+    assert (ids >= 0).any() and (n < 9 or ((ids >= 0) & (ids < n)).any())
+
+
+@pytest.mark.parametrize("n", [40, 5000])
+def test_gpu_sah_builder_depth_bound_on_degenerate_input(oracle, scenes, capi, n):
+    """Nested slivers: the SAH plane peels one sliver off at a time until the depth bound forces medians -- in the one-wave
+    sub-tree builder (40) and in the level kernels (5000).  The tree stays within the traversal stack and renders the oracle's frame."""
+    desc = _sliver_scene(scenes, capi, n)
+    s = scenes.build(desc, 0, capi.BUILD_GPU_SAH)
+    assert s.info().builder == 2 and 0 < s.info().bvh_depth <= 32
+    width, height, spp = 96, 54, 1
+    params, cam = scenes.make_camera(width, lookfrom=(0.3, 1.2, 4.0), lookat=(-0.4, 0.8, 0.0), vfov=40.0)
+    rgb, ids, st = s.render(cam, width, height, spp, want_ids=True)
+    fb, rids, _, rst = oracle.RefScene(desc).render(oracle.make_camera(params, width), width, height, spp)
+    assert np.array_equal(ids, rids) and np.array_equal(rgb.reshape(fb.shape), fb) and st.rays == rst.rays
+    assert ((ids >= 0) & (ids < n)).any()
 
 
 def test_randomised_configurations_against_oracle(oracle, scenes, gpu_scenes, capi, node_cache):
@@ -489,11 +584,12 @@ def test_degenerate_trees(oracle, scenes, capi, node_cache, kind):
     assert (ids >= 0).any()
 
 
+@pytest.mark.parametrize("builder", ["lbvh", "sah"])
 @pytest.mark.parametrize("kind", ["spheres_only", "one_triangle", "three_triangles"])
-def test_degenerate_trees_from_the_gpu_builder(oracle, scenes, capi, kind):
-    """The same degenerate scenes committed through the GPU builder (a scene without triangles has nothing to build there)."""
+def test_degenerate_trees_from_the_gpu_builder(oracle, scenes, capi, kind, builder):
+    """The same degenerate scenes committed through the GPU builders (a scene without triangles has nothing to build there)."""
     desc = _degenerate_scene(scenes, capi, kind)
-    s = scenes.build(desc, 0, flags=capi.BUILD_GPU_LBVH)
+    s = scenes.build(desc, 0, flags=capi.BUILD_GPU_LBVH if builder == "lbvh" else capi.BUILD_GPU_SAH)
     width, height, spp = 96, 54, 2
     params, cam = scenes.make_camera(width)
     rgb, ids, st = s.render(cam, width, height, spp, want_ids=True)
