@@ -805,6 +805,41 @@ def test_full_size_properties_3840x2160(scenes, gpu_scenes, capi, workload):
     assert np.isfinite(img).all() and img.min() >= 0 and img.mean() > 0.01
 
 
+def test_config5_at_its_own_sample_count_3840x2160x1024(scenes, gpu_scenes, capi):
+    """BASELINE config 5 in full: cats at 3840 x 2160 with 1024 samples per pixel (8.5 G primary rays; half a second per frame).
+    One sample per work unit -- 3.3 TB as slabs, so the frame goes through the waves' rings -- must equal the whole-pixel
+    frame (the reference's sequential sum, renderer.h:26-32, the path checked against the oracle at small sizes) bit for
+    bit; and the sample split the config names (8 ranks x 128 samples, raw sums added in rank order, then / spp and gamma)
+    must account for every ray and agree with the full frame to float association (tolerance: 8e-6 relative on the
+    gamma-encoded value, stated where it is asserted)."""
+    import torch
+    _, s = gpu_scenes("cats")
+    W, H, spp, ranks = 3840, 2160, 1024, 8
+    _, cam = scenes.make_camera(W)
+    dev = capi.OUT_DEVICE
+    a = torch.empty(H * W * 3, dtype=torch.float32, device="cuda")
+    b = torch.zeros_like(a)
+    st_a = s.render(cam, W, H, spp, out_rgb=a.data_ptr(), sample_chunks=spp, flags=dev)[2]
+    st_w = s.render(cam, W, H, spp, out_rgb=b.data_ptr(), flags=dev)[2]
+    torch.cuda.synchronize()
+    assert st_a.rays == st_w.rays and torch.equal(a, b)
+    print("4K x 1024 spp: %.0f ms with one sample per unit, %.0f ms with whole pixels, %.1f Grays/s" % (st_a.kernel_ms, st_w.kernel_ms, st_a.rays / st_a.kernel_ms / 1e6))
+    acc = torch.zeros_like(a)
+    part = torch.empty_like(a)
+    rays = 0
+    for r in range(ranks):
+        rays += s.render(cam, W, H, spp // ranks, sample_offset=r * (spp // ranks), flags=capi.OUT_ACCUM | dev, out_rgb=part.data_ptr(), sample_chunks=64)[2].rays
+        torch.cuda.synchronize()
+        acc += part
+    capi.finalize(acc.data_ptr(), W, H, spp, b.data_ptr())
+    torch.cuda.synchronize()
+    # 1024 positive terms added in another association: the sums differ by a few sqrt(n) * 2^-24 relative (worst case n * 2^-24),
+    # halved by the gamma's square root; measured 2e-6 at most
+    rel = ((a - b).abs() / b.abs().clamp_min(1e-3)).max().item()
+    print("sample split 8 x 128 against the sequential sum: largest relative difference %.2e" % rel)
+    assert rays == st_a.rays and torch.allclose(a, b, rtol=8e-6, atol=1e-6)
+
+
 _TWO_PART_OBJ = """# two objects, two materials, one of them emissive (row N4: crt_load_obj_ex + .mtl records)
 mtllib parts.mtl
 o body
