@@ -509,6 +509,19 @@ extern "C" int crt_scene_add_sphere(crt_scene *s, const float center[3], float r
     return CRT_OK;
 }
 
+// CRT_PRINT_COMMIT=1: where a commit's wall time goes, stage by stage, on stderr
+struct CommitClock {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    const bool on = getenv("CRT_PRINT_COMMIT") != nullptr;
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "crt commit: %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
+
 template <class T>
 static int upload(void **dst, const std::vector<T> &v)
 {
@@ -525,6 +538,7 @@ static bool commit_gpu_lbvh(crt_scene *s, int device, uint32_t max_leaf, uint32_
     if (device < 0 || s->tris.empty() || s->spheres.size() > 8 || s->tris.size() >= (1u << 28)) return false;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev || hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return false; }
+    CommitClock clk;
     const size_t n = s->tris.size();
     std::vector<float> tri9(n * 9);
     std::vector<int> mat(n);
@@ -547,10 +561,12 @@ static bool commit_gpu_lbvh(crt_scene *s, int device, uint32_t max_leaf, uint32_
         }
     }
     LbvhOutput out;
+    clk.lap("pack triangles");
     if (lbvh_build(tri9.data(), mat.data(), (uint32_t)n, su, !sph.empty(), sph.data(), (uint32_t)sph.size(), max_leaf, tree_kind, out, nullptr) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
+    clk.lap("device build + transfers");
     if (out.depth > CRT_STACK_DEPTH) return false; // long runs of equal codes: the host builder bounds the depth
     // ranks: triangles from the device; a sphere follows every triangle with a code <= its own (stable sort, triangles
     // first in the reference's list) and the spheres that sort before it
@@ -563,11 +579,13 @@ static bool commit_gpu_lbvh(crt_scene *s, int device, uint32_t max_leaf, uint32_
         s->rank[n + k] = r;
     }
     s->bvh = FlatBvh();
-    renumber_breadth_first(out.nodes, out.root_ref); // Karras numbering -> breadth first (the top of the tree goes to LDS)
+    if (!out.breadth_first) renumber_breadth_first(out.nodes, out.root_ref); // Karras numbering -> breadth first (the top of the tree goes to LDS)
+    s->normals.swap(out.normals); // (SAH builder: made on the device with the slots; else empty)
     s->bvh.nodes.swap(out.nodes);
     s->bvh.tris.swap(out.slots);
     s->bvh.root_ref = out.root_ref; s->bvh.root_box = out.root_box; s->bvh.depth = out.depth; s->bvh.max_leaf = max_leaf;
     s->builder = tree_kind == LBVH_TREE_SAH ? 2u : 1u; s->build_ms = out.build_ms;
+    clk.lap("sphere ranks + renumbering");
     return true;
 }
 
@@ -603,6 +621,7 @@ static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
     const uint32_t max_leaf = (uint32_t)get_env_int("CRT_MAX_LEAF", 2);
     s->builder = 0; s->build_ms = 0.0f;
     flags = resolve_builder(s, build_device, flags);
+    CommitClock clk;
     const bool gpu_built = (flags & (CRT_BUILD_GPU_LBVH | CRT_BUILD_GPU_SAH)) &&
                            commit_gpu_lbvh(s, build_device, std::min(std::max(max_leaf, 1u), 8u), (flags & CRT_BUILD_GPU_SAH) ? LBVH_TREE_SAH : LBVH_TREE_KARRAS);
     const auto host_t0 = std::chrono::steady_clock::now();
@@ -649,6 +668,7 @@ static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
         build_bvh(s->tris, s->rank, tree_spheres, max_leaf, s->bvh);
         s->build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
     }
+    clk.lap("ranks + tree");
     if (s->bvh.depth > CRT_STACK_DEPTH) return fail(CRT_ERR_LIMIT, "crt_scene_commit: BVH deeper than the traversal stack");
     // Four children per node (CRT_BVH_WIDE=1): half the levels, half the node fetches per ray, and 2.3 times the instructions per
     // fetch -- the kernel is bound by instruction issue, not by the latency of dependent fetches, so the two-child format stays
@@ -681,8 +701,9 @@ static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
     // the unit normal of every triangle slot, with the operations the hit record uses (sphere slots: unused)
     {
         const size_t nslots = s->bvh.tris.size() / 3;
-        s->normals.resize(nslots);
-        for (size_t k = 0; k < nslots; k++) {
+        const bool have = gpu_built && s->normals.size() == nslots && nslots > 0;
+        if (!have) s->normals.resize(nslots);
+        for (size_t k = 0; k < nslots && !have; k++) {
             const q4 *tp = &s->bvh.tris[3 * k];
             int rank_word;
             std::memcpy(&rank_word, &tp[1].w, 4);
@@ -690,6 +711,7 @@ static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
             else s->normals[k] = triangle_normal(tp[0], tp[1], tp[2]);
         }
     }
+    clk.lap("shading records + normals");
     s->prepared = true;
     return CRT_OK;
 }
@@ -742,7 +764,9 @@ extern "C" int crt_scene_commit_ex(crt_scene *s, int device, uint32_t flags)
     if (rc) return rc;
     if (device == CRT_DEVICE_NONE) return CRT_OK; // host-side preparation only (ranks, BVH); rendering stays unavailable
     s->dev.resize(1);
+    CommitClock clk;
     if ((rc = upload_replica(s, s->dev[0], device))) { s->release_device(); return rc; }
+    clk.lap("upload");
     s->device = device;
     s->committed = true;
     return CRT_OK;

@@ -21,6 +21,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include "crt_bvh.h"
@@ -53,7 +54,8 @@ struct SahSplit {     // what the evaluation decided for an active node
     uint32_t nleft;
     int child[2];     // index in the next level's list, or -1: the child is small (or nothing to do)
 };
-struct Counters { uint32_t small, nodes, depth, pad; uint32_t active[MAX_LEVELS + 2]; };
+struct Counters { uint32_t small, nodes, depth, used; uint32_t active[MAX_LEVELS + 2]; };
+constexpr uint32_t DEPTH_WORD = 11;      // q[2].w of a record: unused by the kernels (the children's boxes and references take the rest)
 
 __device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : u | 0x80000000u; }
 __device__ __forceinline__ float ord2f(uint32_t o) { return __uint_as_float((o & 0x80000000u) ? o & 0x7FFFFFFFu : ~o); }
@@ -239,6 +241,8 @@ __global__ __launch_bounds__(256) void gsah_eval_kernel(const SahNode *__restric
     if (lane != 0) return;
     const uint32_t rec = atomicAdd(&ctr->nodes, 1u);
     write_child(records, nd.parent, side, box, (int)rec);
+    ((uint32_t *)&records[4 * (size_t)rec])[DEPTH_WORD] = depth; // (a free word of the record: the breadth-first renumbering sorts by it)
+    atomicAdd(&ctr->used, 1u);
     atomicMax(&ctr->depth, depth);
     SahSplit sp;
     sp.axis_bin = axis_bin; sp.nleft = nleft;
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(64) void gsah_small_kernel(const SahNode *__restric
     uint32_t rec_next = 0;
     if (lane == 0 && n > 1) rec_next = atomicAdd(&ctr->nodes, n - 1u);
     rec_next = (uint32_t)__shfl((int)rec_next, 0, 64);
-    uint32_t deepest = 0;
+    uint32_t deepest = 0, used = 0;
     int sp = 0;
     if (lane == 0) { stack[0] = 0u | n << 8; stack[1] = nd.parent; stack[2] = nd.meta; }
     sp = 1;
@@ -382,7 +386,8 @@ __global__ __launch_bounds__(64) void gsah_small_kernel(const SahNode *__restric
         if (force_median) win = -1;
         const uint32_t rec = rec_next++, below_levels = levels > 0 ? levels - 1u : 0u;
         deepest = max(deepest, depth);
-        if (lane == 0) write_child(records, parent, side, box, (int)rec);
+        if (lane == 0) { write_child(records, parent, side, box, (int)rec); ((uint32_t *)&records[4 * (size_t)rec])[DEPTH_WORD] = depth; }
+        used++;
         uint32_t nleft = m / 2;
         bool left = in && (uint32_t)lane - lo < nleft;
         if (win >= 0) {
@@ -409,12 +414,12 @@ __global__ __launch_bounds__(64) void gsah_small_kernel(const SahNode *__restric
         }
     }
     if ((uint32_t)lane < n) pid[nd.lo + (uint32_t)lane] = id;
-    if (lane == 0 && deepest > 0) atomicMax(&ctr->depth, deepest);
+    if (lane == 0 && deepest > 0) { atomicMax(&ctr->depth, deepest); atomicAdd(&ctr->used, used); }
 }
 
 // the 48-byte slots in final position order
 __global__ __launch_bounds__(256) void gsah_slots_kernel(const float *__restrict__ tri9, const int *__restrict__ mat, const uint32_t *__restrict__ rank_of_tri,
-                                                         const uint32_t *__restrict__ pid, uint32_t n, q4 *__restrict__ slots)
+                                                         const uint32_t *__restrict__ pid, uint32_t n, q4 *__restrict__ slots, q4 *__restrict__ normals)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n) return;
@@ -425,12 +430,43 @@ __global__ __launch_bounds__(256) void gsah_slots_kernel(const float *__restrict
     b.x = v[3]; b.y = v[4]; b.z = v[5]; b.w = __int_as_float((int)rank_of_tri[t]);
     c.x = v[6]; c.y = v[7]; c.z = v[8]; c.w = __int_as_float(mat[t]);
     slots[3 * (size_t)p + 0] = a; slots[3 * (size_t)p + 1] = b; slots[3 * (size_t)p + 2] = c;
+    normals[p] = triangle_normal(a, b, c); // the hit record's normal (triangle.h:81), the host's operations (crt_traverse.h), once per slot
+}
+
+// Breadth-first numbering on the device: records sorted by depth (stable: a level keeps its allocation order), so that "index
+// < N" means "one of the N nodes nearest the root" as renumber_breadth_first (crt_bvh.cpp) guarantees for the host's trees.
+__global__ __launch_bounds__(256) void gsah_depth_keys_kernel(const q4 *__restrict__ records, uint32_t nrec, uint32_t *__restrict__ key, uint32_t *__restrict__ val)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nrec) return;
+    const uint32_t d = ((const uint32_t *)&records[4 * (size_t)i])[DEPTH_WORD];
+    key[i] = d ? d : 63u; // records a small node reserved and did not need: behind everything
+    val[i] = i;
+}
+__global__ __launch_bounds__(256) void gsah_inverse_kernel(const uint32_t *__restrict__ order, uint32_t nrec, uint32_t *__restrict__ renum)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j < nrec) renum[order[j]] = j;
+}
+__global__ __launch_bounds__(256) void gsah_renumber_kernel(const q4 *__restrict__ records, const uint32_t *__restrict__ order, const uint32_t *__restrict__ renum,
+                                                            uint32_t used, q4 *__restrict__ out)
+{
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+    if (j >= used) return;
+    const q4 *src = &records[4 * (size_t)order[j]];
+    q4 q[4] = { src[0], src[1], src[2], src[3] };
+    int r0 = __float_as_int(q[0].w), r1 = __float_as_int(q[1].w);
+    if (r0 >= 0) r0 = (int)renum[r0];
+    if (r1 >= 0) r1 = (int)renum[r1];
+    q[0].w = __int_as_float(r0); q[1].w = __int_as_float(r1); q[2].w = 0.0f; q[3].w = 0.0f;
+    for (int k = 0; k < 4; k++) out[4 * (size_t)j + k] = q[k];
 }
 
 } // namespace
 
 hipError_t gsah_build(const float *d_tri9, const int *d_mat, const float *d_refbox6, const uint32_t *d_order, const uint32_t *d_rank_of_tri, uint32_t n,
-                      float margin, const float tri_box[6], uint32_t max_leaf, float tri_cost, q4 *d_records, q4 *d_slots, GsahResult &res, hipStream_t stream)
+                      float margin, const float tri_box[6], uint32_t max_leaf, float tri_cost, q4 *d_records, q4 *d_nodes_out, q4 *d_slots, q4 *d_normals, GsahResult &res,
+                      hipStream_t stream)
 {
     Box6 *pbox[2] = { nullptr, nullptr };
     uint32_t *pid[2] = { nullptr, nullptr }, *d_flag = nullptr, *d_scan = nullptr, *d_gbins = nullptr;
@@ -498,15 +534,35 @@ hipError_t gsah_build(const float *d_tri9, const int *d_mat, const float *d_refb
         hipLaunchKernelGGL(gsah_small_kernel, dim3(nsmall), dim3(64), 0, stream, d_small, pbox[cur], pid[cur], max_leaf, tri_cost, d_records, d_ctr);
         GSAH_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(gsah_slots_kernel, dim3(blocks), dim3(256), 0, stream, d_tri9, d_mat, d_rank_of_tri, pid[cur], n, d_slots);
+    hipLaunchKernelGGL(gsah_slots_kernel, dim3(blocks), dim3(256), 0, stream, d_tri9, d_mat, d_rank_of_tri, pid[cur], n, d_slots, d_normals);
     GSAH_TRY(hipGetLastError());
     Counters h;
     q4 above[4];
     GSAH_TRY(hipMemcpyAsync(&h, d_ctr, sizeof h, hipMemcpyDeviceToHost, stream));
     GSAH_TRY(hipMemcpyAsync(above, d_records + 4 * (size_t)n, sizeof above, hipMemcpyDeviceToHost, stream));
     GSAH_TRY(hipStreamSynchronize(stream));
-    res.num_records = h.nodes; res.depth = h.depth; res.levels_run = levels_run; res.small_nodes = h.small;
+    if (h.nodes > 0) { // breadth-first numbering; the tier-A buffers are free by now: keys / values of the sort live in them
+        if (h.nodes >= n || h.used > h.nodes) { cleanup(); return hipErrorUnknown; }
+        uint32_t *key_in = d_flag, *key_out = d_scan, *val_in = pid[cur ^ 1], *val_out = (uint32_t *)node_of[0], *renum = (uint32_t *)node_of[1];
+        const uint32_t rb = (h.nodes + 255u) / 256u;
+        hipLaunchKernelGGL(gsah_depth_keys_kernel, dim3(rb), dim3(256), 0, stream, d_records, h.nodes, key_in, val_in);
+        size_t sort_bytes = 0;
+        void *d_sort = nullptr;
+        GSAH_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, key_in, key_out, val_in, val_out, (size_t)h.nodes, 0u, 6u, stream));
+        GSAH_TRY(hipMalloc(&d_sort, sort_bytes ? sort_bytes : 16));
+        hipError_t e = rocprim::radix_sort_pairs(d_sort, sort_bytes, key_in, key_out, val_in, val_out, (size_t)h.nodes, 0u, 6u, stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(gsah_inverse_kernel, dim3(rb), dim3(256), 0, stream, val_out, h.nodes, renum);
+            hipLaunchKernelGGL(gsah_renumber_kernel, dim3((h.used + 255u) / 256u), dim3(256), 0, stream, d_records, val_out, renum, h.used, d_nodes_out);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        (void)hipFree(d_sort);
+        GSAH_TRY(e);
+    }
+    res.num_records = h.used; res.depth = h.depth; res.levels_run = levels_run; res.small_nodes = h.small;
     std::memcpy(&res.root_ref, &above[0].w, 4);
+    if (res.root_ref >= 0) res.root_ref = 0; // the root is the one record of depth 1: first after the sort
     res.root_box.mn = mk3(above[0].x, above[0].y, above[0].z);
     res.root_box.mx = mk3(above[1].x, above[1].y, above[1].z);
     cleanup();

@@ -15,6 +15,8 @@ struct LbvhSphereInput { Box refbox; };                       // reference box o
 struct LbvhOutput {
     std::vector<q4> nodes;              // 4 per node, Karras numbering / allocation order (records of collapsed sub-trees are zero)
     std::vector<q4> slots;              // 3 per triangle, in sorted (rank) order
+    std::vector<q4> normals;            // per slot (SAH tree only; else empty: the host computes them)
+    bool breadth_first = false;         // nodes are numbered breadth first already (SAH tree)
     std::vector<uint32_t> rank_of_tri;  // global rank of triangle i
     std::vector<uint32_t> sorted_codes; // the triangles' codes in sorted order (for the spheres' ranks)
     LbvhSphereCodes sphere_codes{};
@@ -32,11 +34,13 @@ enum { LBVH_TREE_KARRAS = 0, LBVH_TREE_SAH = 1 };
 
 // crt_gsah.hip: binned-SAH tree over n triangles on the device.  d_refbox6: the reference boxes (6 floats each, min xyz max
 // xyz); d_order: a starting order of the triangles (any permutation; Morton order makes the rare median splits spatial);
-// tri_box: union of the reference boxes.  Writes the node records (room for n + 1: record n receives the root's box and
-// reference) and the 48-byte slots in leaf order.
+// tri_box: union of the reference boxes.  d_records: scratch for n + 1 records (allocation order; record n receives the root's
+// box and reference); d_nodes_out: the res.num_records nodes in breadth-first numbering (room for n); d_slots / d_normals: the
+// 48-byte slots and their unit normals (crt_traverse.h: triangle_normal) in leaf order.
 struct GsahResult { uint32_t num_records = 0, depth = 0, levels_run = 0, small_nodes = 0; int root_ref = CRT_BVH_NONE; Box root_box{}; };
 hipError_t gsah_build(const float *d_tri9, const int *d_mat, const float *d_refbox6, const uint32_t *d_order, const uint32_t *d_rank_of_tri, uint32_t n,
-                      float margin, const float tri_box[6], uint32_t max_leaf, float tri_cost, q4 *d_records, q4 *d_slots, GsahResult &res, hipStream_t stream);
+                      float margin, const float tri_box[6], uint32_t max_leaf, float tri_cost, q4 *d_records, q4 *d_nodes_out, q4 *d_slots, q4 *d_normals, GsahResult &res,
+                      hipStream_t stream);
 
 // h_tri9: 9 floats per triangle (a, b, c); h_mat: material per triangle.  sphere_union: union of the spheres' reference
 // boxes (have_spheres false: none).  At most 8 spheres.  The device is the current one.

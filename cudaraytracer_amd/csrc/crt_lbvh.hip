@@ -282,12 +282,12 @@ hipError_t lbvh_build(const float *h_tri9, const int *h_mat, uint32_t n, const B
     uint32_t *d_rank = nullptr, *d_depth = nullptr;
     unsigned long long *d_code64 = nullptr, *d_code64_s = nullptr;
     void *d_temp64 = nullptr;
-    q4 *d_nodes = nullptr, *d_slots = nullptr;
+    q4 *d_nodes = nullptr, *d_slots = nullptr, *d_nodes_bf = nullptr, *d_normals = nullptr;
     void *d_temp = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() {
         void *ptrs[] = { d_tri9, d_mat, d_refbox, d_leafbox, d_nodebox, d_red, d_code, d_idx, d_code_s, d_idx_s, d_child0, d_child1, d_first, d_last, d_pnode,
-                         d_pleaf, d_flags, d_rank, d_depth, d_nodes, d_slots, d_temp, d_code64, d_code64_s, d_temp64 };
+                         d_pleaf, d_flags, d_rank, d_depth, d_nodes, d_slots, d_temp, d_code64, d_code64_s, d_temp64, d_nodes_bf, d_normals };
         for (void *p : ptrs) if (p) (void)hipFree(p);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
@@ -373,7 +373,9 @@ hipError_t lbvh_build(const float *h_tri9, const int *h_mat, uint32_t n, const B
         const float tri_box[6] = { ord2f(red[0]), ord2f(red[1]), ord2f(red[2]), ord2f(red[3]), ord2f(red[4]), ord2f(red[5]) };
         float tri_cost = 1.3f; // crt_bvh.cpp: Builder::TRI_COST
         if (const char *e = getenv("CRT_SAH_TRI_COST")) tri_cost = (float)atof(e);
-        LBVH_TRY(gsah_build(d_tri9, d_mat, (const float *)d_refbox, d_idx_s, d_rank, n, margin, tri_box, max_leaf, tri_cost, d_nodes, d_slots, sah, stream));
+        LBVH_TRY(hipMalloc((void **)&d_nodes_bf, (size_t)n * 4 * sizeof(q4)));
+        LBVH_TRY(hipMalloc((void **)&d_normals, (size_t)n * sizeof(q4)));
+        LBVH_TRY(gsah_build(d_tri9, d_mat, (const float *)d_refbox, d_idx_s, d_rank, n, margin, tri_box, max_leaf, tri_cost, d_nodes, d_nodes_bf, d_slots, d_normals, sah, stream));
     } else {
         if (n > 1) {
             hipLaunchKernelGGL(hierarchy_kernel, dim3((n - 1 + 255u) / 256u), dim3(256), 0, stream, d_code64_s, (int)n, d_child0, d_child1, d_first, d_last, d_pnode, d_pleaf);
@@ -403,7 +405,10 @@ hipError_t lbvh_build(const float *h_tri9, const int *h_mat, uint32_t n, const B
     uint32_t depth = 0;
     if (tree_kind == LBVH_TREE_SAH) {
         out.nodes.resize((size_t)sah.num_records * 4);
-        if (sah.num_records) LBVH_TRY(hipMemcpyAsync(out.nodes.data(), d_nodes, (size_t)sah.num_records * 4 * sizeof(q4), hipMemcpyDeviceToHost, stream));
+        if (sah.num_records) LBVH_TRY(hipMemcpyAsync(out.nodes.data(), d_nodes_bf, (size_t)sah.num_records * 4 * sizeof(q4), hipMemcpyDeviceToHost, stream));
+        out.normals.resize(n);
+        LBVH_TRY(hipMemcpyAsync(out.normals.data(), d_normals, (size_t)n * sizeof(q4), hipMemcpyDeviceToHost, stream));
+        out.breadth_first = true;
         out.root_ref = sah.root_ref;
         LBVH_TRY(hipStreamSynchronize(stream));
         out.root_box = sah.root_box;
