@@ -126,7 +126,7 @@ typedef struct crt_scene_info {
     uint64_t node_bytes, triangle_bytes, sphere_bytes; /* resident HBM footprint */
     float bounds_min[3], bounds_max[3];                /* triangle BVH root box  */
     uint32_t builder;        /* 0 = host SAH, 1 = GPU LBVH, 2 = GPU SAH                                      */
-    float build_ms;          /* GPU LBVH: hipEvent time of the build kernels and the sort; host SAH: wall time */
+    float build_ms;          /* GPU builders: hipEvent time of the build kernels and the sorts; host SAH: wall time */
     uint32_t node_width;     /* 2; 4 when the scene was committed with CRT_BVH_WIDE=1 in the environment (four-child nodes: an option, slower) */
     uint32_t binary_depth;   /* depth of the two-child tree the builder made (= bvh_depth when node_width is 2)                          */
     float sah_cost;          /* surface-area cost of the two-child tree: expected node visits + 1.3 x triangle tests of a ray that hits the root box */
