@@ -4,12 +4,14 @@
 #include "crt_lbvh.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <numeric>
+#include <thread>
 
 namespace crt {
 
@@ -455,13 +457,26 @@ float reciprocal_if_exact(float s)
         if (known.size() >= 256) return 0.0f; // a scene with that many different radii: the rest divide the ordinary way
     }
     const float y = 1.0f / s;
-    bool exact = true;
-    for (uint32_t m = 0; m < (1u << 23) && exact; m++) { // every significand at one exponent; both signs behave alike
-        const uint32_t bits = 0x40000000u | m;
-        float a;
-        std::memcpy(&a, &bits, 4);
-        const float q = a * y, got = __builtin_fmaf(__builtin_fmaf(-s, q, a), y, q), want = a / s;
-        exact = std::memcmp(&got, &want, 4) == 0;
+    // every significand at one exponent (both signs behave alike), shared among a few threads: 2^23 cases take 65 ms on one core,
+    // and a scene's first commit checks each of its radii
+    const unsigned hw = std::thread::hardware_concurrency();
+    const uint32_t nthreads = std::min(std::max(hw, 1u), 8u), total = 1u << 23, per = total / nthreads;
+    std::atomic<bool> exact{ true };
+    auto check = [&](uint32_t m0, uint32_t m1) {
+        for (uint32_t m = m0; m < m1; m++) {
+            if ((m & 0xFFFFu) == 0 && !exact.load(std::memory_order_relaxed)) return; // (someone found a counter-example)
+            const uint32_t bits = 0x40000000u | m;
+            float a;
+            std::memcpy(&a, &bits, 4);
+            const float q = a * y, got = __builtin_fmaf(__builtin_fmaf(-s, q, a), y, q), want = a / s;
+            if (std::memcmp(&got, &want, 4) != 0) { exact.store(false, std::memory_order_relaxed); return; }
+        }
+    };
+    {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < nthreads; t++) pool.emplace_back(check, t * per, t + 1 == nthreads ? total : (t + 1) * per);
+        check(0, nthreads == 1 ? total : per);
+        for (std::thread &t : pool) t.join();
     }
     const float result = exact ? y : 0.0f;
     std::lock_guard<std::mutex> lock(mutex);
