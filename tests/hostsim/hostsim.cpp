@@ -12,7 +12,7 @@ hipError_t launch_render(const SceneView &, const CameraPOD &, const RenderArgs 
 }
 hipError_t launch_untile(const float *, uint32_t, uint32_t, uint32_t, float *, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_finalize(const float *, size_t, uint32_t, float *, hipStream_t) { return hipErrorNoDevice; }
-hipError_t lbvh_build(const float *, const int *, uint32_t, const Box &, bool, const LbvhSphereInput *, uint32_t, uint32_t, LbvhOutput &, hipStream_t) { return hipErrorNoDevice; }
+hipError_t lbvh_build(const float *, const int *, uint32_t, const Box &, bool, const LbvhSphereInput *, uint32_t, uint32_t, uint32_t, LbvhOutput &, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_quantize(const float *, size_t, uint8_t *, hipStream_t) { return hipErrorNoDevice; }
 hipError_t launch_finalize_chunks(const float *, uint32_t, size_t, uint32_t, bool, float *, hipStream_t) { return hipErrorNoDevice; }
 size_t render_ring_bytes(const RenderArgs &, uint32_t, uint32_t) { return 0; }
