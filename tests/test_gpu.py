@@ -432,6 +432,45 @@ def test_gpu_sah_builder_sizes_around_one_wave(oracle, scenes, capi, n):
     assert (ids >= 0).any() and (n < 9 or ((ids >= 0) & (ids < n)).any())
 
 
+@pytest.mark.parametrize("kind", ["random", "coincident", "line"])
+def test_gpu_sah_builder_on_awkward_large_inputs(oracle, scenes, capi, kind):
+    """Inputs of 40,000 triangles (more than CRT_BUILD_AUTO's limit, so crt_scene_commit itself sends them to the device): a random
+    soup, 40,000 triangles whose boxes share ONE centre (no plane separates anything: medians all the way down, in both tiers), and triangles
+    strung along a line (two axes without extent).  Ranks are the host's, the tree fits the stack, the frame is the oracle's."""
+    n = 40000
+    rng = np.random.default_rng(7)
+    d = scenes._base()
+    d["materials"].append(dict(type=capi.MAT_LAMBERTIAN, rgb=(0.7, 0.3, 0.16), param=0.0, texture=None))
+    scenes._add_ref_spheres(d)
+    if kind == "random":
+        c = rng.uniform(-2.0, 2.0, size=(n, 1, 3)).astype(np.float32) * np.array([1.0, 0.4, 1.0], np.float32) + np.array([0.0, 1.2, 0.0], np.float32)
+        v = c + rng.uniform(-0.05, 0.05, size=(n, 3, 3)).astype(np.float32)
+    elif kind == "coincident":
+        # boxes of every size around ONE centre (extents on a 2^-10 grid, so the centres are equal bit for bit), triangles that
+        # cross each other rather than coincide (coincident ones would all tie: 40,000 candidates per fold)
+        e = (rng.integers(64, 1024, size=(n, 3)) / 1024.0).astype(np.float32)
+        f = (rng.uniform(-1.0, 1.0, size=(n, 3)).astype(np.float32) * e)
+        c0 = np.array([0.0, 1.25, 0.0], np.float32)
+        v = np.stack([np.stack([-e[:, 0], -e[:, 1], f[:, 2]], -1), np.stack([e[:, 0], f[:, 1], -e[:, 2]], -1), np.stack([f[:, 0], e[:, 1], e[:, 2]], -1)], 1) + c0
+    else:
+        x = np.linspace(-3.0, 3.0, n, dtype=np.float32)
+        v = np.stack([np.stack([x, 0 * x + 0.5, 0 * x], -1), np.stack([x + 0.01, 0 * x + 0.5, 0 * x], -1), np.stack([x, 0 * x + 1.5, 0 * x], -1)], 1)
+    d["meshes"].append(dict(vertices=np.ascontiguousarray(v.reshape(3 * n, 3), dtype=np.float32), indices=np.arange(3 * n, dtype=np.uint32).reshape(n, 3), material=0))
+    s = scenes.build(d, 0)
+    host = scenes.build(d, 0, 0)
+    i = s.info()
+    assert i.builder == 2 and host.info().builder == 0 and 0 < i.bvh_depth <= 32 and i.num_triangles == n
+    assert np.array_equal(s.ranks(), host.ranks())
+    width, height, spp = 96, 54, 1
+    params, cam = scenes.make_camera(width)
+    rgb, ids, st = s.render(cam, width, height, spp, want_ids=True)
+    rgb_h, ids_h, st_h = host.render(cam, width, height, spp, want_ids=True)
+    assert np.array_equal(ids, ids_h) and np.array_equal(rgb, rgb_h) and st.rays == st_h.rays
+    fb, rids, _, rst = oracle.RefScene(d).render(oracle.make_camera(params, width), width, height, spp)
+    assert np.array_equal(ids, rids) and np.array_equal(rgb.reshape(fb.shape), fb) and st.rays == rst.rays
+    assert ((ids >= 0) & (ids < n)).any()
+
+
 @pytest.mark.parametrize("n", [40, 5000])
 def test_gpu_sah_builder_depth_bound_on_degenerate_input(oracle, scenes, capi, n):
     """Nested slivers: the SAH plane peels one sliver off at a time until the depth bound forces medians -- in the one-wave
