@@ -104,7 +104,8 @@ struct Search {
     int mat;       // material id of `code` (carried so that the shading record is fetched without waiting for the primitive)
     int rank;      // MODE_NEXT_RANK: rank of the candidate found (smallest rank > after_rank)
     int near_tie;  // MODE_CLOSEST: 1 when two candidates within CRT_TIE_WINDOW of each other were seen (an int: a lane
-                   // mask would be merged with scalar instructions at every join of the walk loop)
+                   // mask would be merged with scalar instructions at every join of the walk loop).  MODE_NEXT_RANK: 0, or -1 to
+                   // search for the largest rank instead (`rank` then holds ~rank, and after_rank must be INT_MIN)
 };
 
 template <int MODE>
@@ -114,7 +115,9 @@ CRT_HD void offer(Search &s, float t, int code, int mat, int rank, int after_ran
         s.near_tie = (s.code >= 0 && __builtin_fabsf(t - s.t) <= CRT_TIE_WINDOW) ? 1 : s.near_tie;
         if (t < s.t) { s.t = t; s.code = code; s.mat = mat; }
     } else {
-        if (t <= t_hi && rank > after_rank && rank < s.rank) { s.t = t; s.code = code; s.mat = mat; s.rank = rank; }
+        // (s.near_tie, unused in this mode, is the order mask: 0 = smallest rank, -1 = the comparison reversed, i.e. the LARGEST rank)
+        const int key = rank ^ s.near_tie;
+        if (t <= t_hi && key > after_rank && key < s.rank) { s.t = t; s.code = code; s.mat = mat; s.rank = key; }
     }
 }
 
@@ -442,6 +445,14 @@ CRT_HD int refold(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float
     float t_hi = t_min + CRT_TIE_WINDOW;
     float closest = tmax;
     int win = -1;
+    // The very first walk looks for the LAST candidate of the window in rank order, L.  Whenever the reference visits L its
+    // `closest` is the t of some candidate, i.e. >= t_min, so L is certainly accepted if it would be against t_min itself; and
+    // if nothing behind L in rank order can be accepted after it (everything the window holds comes before L, and what a
+    // triangle behind it could reach, t_L + 1e-7, is inside the window) L is the reference's answer -- without visiting the
+    // other candidates.  That is the common tie (a shared edge, a doubled face: equal t), and it keeps k primitives that
+    // coincide exactly from costing k walks of k leaves each.  Otherwise: the fold proper, below.  (One call site for both
+    // kinds of walk: the walk is inlined, and the kernel holds this code in every variant.)
+    int order = -1;
     for (int pass = 0; pass < 64; pass++) {
         closest = tmax;
         win = -1;
@@ -449,8 +460,17 @@ CRT_HD int refold(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float
         bool seen_min = false;
         float reach = -FLT_MAX;
         for (;;) {
-            n.t = 0.0f; n.code = -1; n.mat = 0; n.rank = 0x7FFFFFFF; n.near_tie = false;
-            walk<MODE_NEXT_RANK, Stack, Counters, WIDE>(sc, o, d, tmin, n, after, t_hi, stack, cnt, tv);
+            n.t = 0.0f; n.code = -1; n.mat = 0; n.rank = 0x7FFFFFFF; n.near_tie = order;
+            walk<MODE_NEXT_RANK, Stack, Counters, WIDE>(sc, o, d, tmin, n, order ? (int)0x80000000 : after, t_hi, stack, cnt, tv);
+            if (order) {
+                order = 0;
+                const bool is_tri = n.code >= 0 && (uint32_t)n.code < sc.ntris;
+                if (n.code >= 0 && (is_tri ? triangle_accepts(n.t, t_min) : sphere_accepts(n.t, t_min)) && !(n.t + 1e-7f > t_hi)) {
+                    closest = n.t; win = n.code; mat_hit = n.mat;
+                    break;
+                }
+                continue;
+            }
             if (n.code < 0) break;
             const bool is_tri = (uint32_t)n.code < sc.ntris;
             seen_min = seen_min || n.t == t_min;

@@ -471,6 +471,25 @@ def test_gpu_sah_builder_on_awkward_large_inputs(oracle, scenes, capi, kind):
     assert ((ids >= 0) & (ids < n)).any()
 
 
+def test_thousands_of_exactly_coincident_triangles(oracle, scenes, capi, node_cache):
+    """4000 exact copies of each of three triangles: every hit is a tie among 4000 (8000 on the shared edge) candidates with equal
+    t, and the reference's winner is the last of them in leaf order.  The fold finds it with one walk for the largest rank
+    (crt_traverse.h: refold); candidate by candidate this frame took minutes.  Ids, image and ray count are the oracle's."""
+    import time
+    from tests.test_host import _stacked_copies
+    copies = 4000
+    desc = _stacked_copies(scenes, capi, copies)
+    s = scenes.build(desc, 0)
+    width, height, spp = 96, 54, 2
+    params, cam = scenes.make_camera(width)
+    t0 = time.perf_counter()
+    rgb, ids, st = s.render(cam, width, height, spp, want_ids=True)
+    seconds = time.perf_counter() - t0
+    fb, rids, _, rst = oracle.RefScene(desc).render(oracle.make_camera(params, width), width, height, spp)
+    assert np.array_equal(ids, rids) and np.array_equal(rgb.reshape(fb.shape), fb) and st.rays == rst.rays
+    assert ((ids >= 0) & (ids < 3 * copies)).sum() > 100 and st.tie_refolds > 100 and seconds < 5.0
+
+
 @pytest.mark.parametrize("n", [40, 5000])
 def test_gpu_sah_builder_depth_bound_on_degenerate_input(oracle, scenes, capi, n):
     """Nested slivers: the SAH plane peels one sliver off at a time until the depth bound forces medians -- in the one-wave

@@ -221,6 +221,40 @@ def test_ties_resolve_in_reference_leaf_order(hostsim, oracle, capi):
     assert np.array_equal(ids, oid) and np.array_equal(fb, out) and st.rays == hs["rays"] and hs["tie_refolds"] > 0
 
 
+def _stacked_copies(scenes, capi, copies):
+    """`copies` exact copies of each of three triangles (two of them sharing an edge), shuffled, + the reference spheres: every hit is
+    a tie among `copies` (or, on the shared edge, 2 x copies) candidates with equal t."""
+    d = scenes._base()
+    d["materials"].append(dict(type=capi.MAT_LAMBERTIAN, rgb=(0.7, 0.3, 0.16), param=0.0, texture=None))
+    scenes._add_ref_spheres(d)
+    base = np.array([[[-1.5, 0.2, 0.0], [0.5, 0.2, 0.3], [-0.4, 2.2, -0.2]], [[0.5, 0.2, 0.3], [1.8, 0.3, -0.5], [-0.4, 2.2, -0.2]],
+                     [[-1.0, 0.1, 1.2], [1.0, 0.1, 1.2], [0.0, 1.0, 1.0]]], np.float32)
+    order = np.random.default_rng(copies).permutation(3 * copies) % 3
+    v = base[order].reshape(-1, 3)
+    d["meshes"].append(dict(vertices=np.ascontiguousarray(v), indices=np.arange(v.shape[0], dtype=np.uint32).reshape(-1, 3), material=0))
+    return d
+
+
+def test_exactly_coincident_primitives_take_one_fold_walk(hostsim, oracle, scenes, capi):
+    """k primitives with equal t: the reference's answer is the last of them in leaf order.  The fold finds it with ONE walk
+    for the largest rank (crt_traverse.h: refold) instead of k walks of k leaves; the frame is the oracle's either way, and the
+    work counters say which way it went."""
+    copies = 150
+    desc = _stacked_copies(scenes, capi, copies)
+    s = hostsim.build(desc)
+    width, height, spp = 64, 36, 2
+    params, cam = scenes.make_camera(width)
+    fb, ids, _, st = oracle.RefScene(desc).render(oracle.make_camera(params, width), width, height, spp)
+    out, oid, hs = hostsim.render(s, cam, width, height, spp)
+    assert np.array_equal(ids, oid) and np.array_equal(fb, out) and st.rays == hs["rays"]
+    hit = (ids >= 0) & (ids < 3 * copies)
+    assert hit.sum() > 50 and hs["tie_refolds"] >= hit.sum()
+    print("coincident copies: %d folds, %d triangle tests, %d rays" % (hs["tie_refolds"], hs["tri_tests"], hs["rays"]))
+    # per fold: the search that raised the flag + one walk for the last rank, each testing the ~150 (300 on the shared edge) copies
+    # under the ray once; the candidate-by-candidate fold would test them 150 times over
+    assert hs["tri_tests"] < 8 * copies * hs["tie_refolds"]  # (measured 7.1; candidate by candidate it is ~150)
+
+
 def test_four_child_nodes_on_the_host(hostsim, oracle, capi, scenes, monkeypatch):
     """CRT_BVH_WIDE=1 (crt_bvh.h: widen_bvh; crt_traverse.h: trav_inner4_from): the collapsed tree walked by the product code on the
     host gives the oracle's frames -- tie scene included, where the fold in leaf order decides every hit -- with about half the
