@@ -37,7 +37,7 @@ constexpr uint32_t SMALL = 64;           // a node of at most this many triangle
 constexpr uint32_t NBINS = 16;
 constexpr uint32_t BIN_WORDS = 13;       // box min xyz, box max xyz, centroid min xyz, centroid max xyz (order-preserving uints), count
 constexpr uint32_t NODE_WORDS = 3 * NBINS * BIN_WORDS; // 624
-constexpr uint32_t RUNS = 8;             // nodes with an LDS table per work-group of the binning kernel
+constexpr uint32_t RUNS = 16;            // nodes with an LDS table per work-group of the binning kernel (1024 positions meet at most 16 nodes of 65+)
 constexpr uint32_t CHUNK = 1024;         // positions per work-group of the binning kernel
 constexpr uint32_t MAX_LEVELS = CRT_STACK_DEPTH;
 
@@ -215,35 +215,61 @@ __device__ __forceinline__ int evaluate_bins(Ptr bins, const float *cb, int lane
     return (uint32_t)(best >> 32) == 0x7F800000u ? -1 : (int)(uint32_t)best;
 }
 
-// one wave per active node: plane, children, this node's record
-__global__ __launch_bounds__(256) void gsah_eval_kernel(const SahNode *__restrict__ nodes, uint32_t nactive, const uint32_t *__restrict__ gbins, uint32_t level,
-                                                        uint32_t max_leaf, SahSplit *__restrict__ splits, SahNode *__restrict__ next, SahNode *__restrict__ small,
-                                                        q4 *__restrict__ records, Counters *__restrict__ ctr)
+// one wave per active node: plane, children, this node's record.  Every node of a level splits (a node of more than 64
+// triangles is no leaf), so its record is rec_base + its index and its depth is the level's: no counter involved.  The
+// children's places in the next level's list / the list of small nodes come from ONE atomic per list and work-group (eight
+// nodes): 15,000 nodes each bumping the same five words took 350 us of a level, atomics on one address being served ~5 ns apart.
+constexpr uint32_t EVAL_WAVES = 8;
+__global__ __launch_bounds__(64 * EVAL_WAVES) void gsah_eval_kernel(const SahNode *__restrict__ nodes, uint32_t nactive, const uint32_t *__restrict__ gbins, uint32_t level,
+                                                                    uint32_t rec_base, uint32_t max_leaf, SahSplit *__restrict__ splits, SahNode *__restrict__ next,
+                                                                    SahNode *__restrict__ small, q4 *__restrict__ records, Counters *__restrict__ ctr)
 {
-    const uint32_t a = blockIdx.x * 4u + threadIdx.x / 64u;
+    __shared__ uint32_t staged[EVAL_WAVES][NODE_WORDS];
+    __shared__ uint32_t want[EVAL_WAVES][2], base[2];
+    const uint32_t wave = threadIdx.x / 64u, a = blockIdx.x * EVAL_WAVES + wave;
     const int lane = (int)(threadIdx.x & 63u);
-    if (a >= nactive) return;
-    const SahNode nd = nodes[a];
+    const bool live = a < nactive;
+    SahNode nd{};
+    if (live) nd = nodes[a];
     const uint32_t n = nd.hi - nd.lo, side = nd.meta & 1u, levels = (nd.meta >> 8) & 0xFFu, depth = (nd.meta >> 16) & 0xFFu;
-    Sweep s;
-    int win = evaluate_bins(gbins + (size_t)a * NODE_WORDS, nd.cb, lane, s);
-    if (levels <= levels_needed(n, max_leaf)) win = -1; // the depth bound: object median from here on
-    float box[6], ccb[2][6];
-    for (int w = 0; w < 6; w++) box[w] = __shfl(s.lbox[w], 15, 64);
+    // the node's bins through LDS: ten coalesced loads per lane instead of 16 x 13 dependent ones
+    uint32_t *mine = staged[wave];
+    if (live) for (uint32_t i = (uint32_t)lane; i < NODE_WORDS; i += 64u) mine[i] = gbins[(size_t)a * NODE_WORDS + i];
+    __syncthreads();
+    float box[6] = { 0, 0, 0, 0, 0, 0 }, ccb[2][6] = { { 0, 0, 0, 0, 0, 0 }, { 0, 0, 0, 0, 0, 0 } };
     uint32_t nleft = n / 2, axis_bin = 0xFFFFFFFFu;
-    if (win >= 0) {
-        nleft = (uint32_t)__shfl((int)s.lcnt, win, 64);
-        axis_bin = (uint32_t)(win / 16) << 8 | (uint32_t)(win & 15);
-        for (int w = 0; w < 6; w++) { ccb[0][w] = __shfl(s.lcb[w], win, 64); ccb[1][w] = __shfl(s.rcb[w], win, 64); }
-    } else {
-        for (int w = 0; w < 6; w++) ccb[0][w] = ccb[1][w] = nd.cb[w];
+    if (live) {
+        Sweep s;
+        int win = evaluate_bins(mine, nd.cb, lane, s);
+        if (levels <= levels_needed(n, max_leaf)) win = -1; // the depth bound: object median from here on
+        for (int w = 0; w < 6; w++) box[w] = __shfl(s.lbox[w], 15, 64);
+        if (win >= 0) {
+            nleft = (uint32_t)__shfl((int)s.lcnt, win, 64);
+            axis_bin = (uint32_t)(win / 16) << 8 | (uint32_t)(win & 15);
+            for (int w = 0; w < 6; w++) { ccb[0][w] = __shfl(s.lcb[w], win, 64); ccb[1][w] = __shfl(s.rcb[w], win, 64); }
+        } else {
+            for (int w = 0; w < 6; w++) ccb[0][w] = ccb[1][w] = nd.cb[w];
+        }
     }
-    if (lane != 0) return;
-    const uint32_t rec = atomicAdd(&ctr->nodes, 1u);
+    const uint32_t size[2] = { nleft, n - nleft };
+    if (lane == 0) {
+        want[wave][0] = live ? (size[0] > SMALL ? 1u : 0u) + (size[1] > SMALL ? 1u : 0u) : 0u;
+        want[wave][1] = live ? (size[0] > SMALL ? 0u : 1u) + (size[1] > SMALL ? 0u : 1u) : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t0 = 0, t1 = 0;
+        for (uint32_t k = 0; k < EVAL_WAVES; k++) { t0 += want[k][0]; t1 += want[k][1]; }
+        base[0] = t0 ? atomicAdd(&ctr->active[level + 1], t0) : 0u;
+        base[1] = t1 ? atomicAdd(&ctr->small, t1) : 0u;
+    }
+    __syncthreads();
+    if (!live || lane != 0) return;
+    uint32_t at[2] = { base[0], base[1] };
+    for (uint32_t k = 0; k < wave; k++) { at[0] += want[k][0]; at[1] += want[k][1]; }
+    const uint32_t rec = rec_base + a;
     write_child(records, nd.parent, side, box, (int)rec);
     ((uint32_t *)&records[4 * (size_t)rec])[DEPTH_WORD] = depth; // (a free word of the record: the breadth-first renumbering sorts by it)
-    atomicAdd(&ctr->used, 1u);
-    atomicMax(&ctr->depth, depth);
     SahSplit sp;
     sp.axis_bin = axis_bin; sp.nleft = nleft;
     for (uint32_t k = 0; k < 2; k++) {
@@ -251,12 +277,8 @@ __global__ __launch_bounds__(256) void gsah_eval_kernel(const SahNode *__restric
         c.lo = k == 0 ? nd.lo : nd.lo + nleft; c.hi = k == 0 ? nd.lo + nleft : nd.hi;
         c.parent = rec; c.meta = k | (levels - 1u) << 8 | (depth + 1u) << 16;
         for (int w = 0; w < 6; w++) c.cb[w] = ccb[k][w];
-        if (c.hi - c.lo > SMALL) {
-            const uint32_t slot = atomicAdd(&ctr->active[level + 1], 1u);
-            next[slot] = c; sp.child[k] = (int)slot;
-        } else {
-            small[atomicAdd(&ctr->small, 1u)] = c; sp.child[k] = -1;
-        }
+        if (size[k] > SMALL) { next[at[0]] = c; sp.child[k] = (int)at[0]++; }
+        else { small[at[1]++] = c; sp.child[k] = -1; }
     }
     splits[a] = sp;
 }
@@ -508,14 +530,15 @@ hipError_t gsah_build(const float *d_tri9, const int *d_mat, const float *d_refb
     hipLaunchKernelGGL(gsah_init_kernel, dim3(blocks), dim3(256), 0, stream, d_refbox6, d_order, n, margin, tiered ? 0 : -1, pbox[0], pid[0], node_of[0]);
     GSAH_TRY(hipGetLastError());
     int cur = 0;
-    uint32_t nactive = tiered ? 1u : 0u, nsmall = tiered ? 0u : 1u, levels_run = 0;
+    uint32_t nactive = tiered ? 1u : 0u, nsmall = tiered ? 0u : 1u, levels_run = 0, level_records = 0;
     for (uint32_t level = 0; nactive > 0; level++) {
         if (level > MAX_LEVELS) { cleanup(); return hipErrorUnknown; } // (cannot happen: the depth bound forces medians)
         const uint32_t words = nactive * NODE_WORDS;
         hipLaunchKernelGGL(gsah_clear_bins_kernel, dim3(std::min((words + 255u) / 256u, 2048u)), dim3(256), 0, stream, d_gbins, words);
         hipLaunchKernelGGL(gsah_bin_kernel, dim3((n + CHUNK - 1u) / CHUNK), dim3(256), 0, stream, pbox[cur], node_of[cur], n, d_nodes[cur], d_gbins);
-        hipLaunchKernelGGL(gsah_eval_kernel, dim3((nactive + 3u) / 4u), dim3(256), 0, stream, d_nodes[cur], nactive, d_gbins, level, max_leaf, d_splits, d_nodes[cur ^ 1],
-                           d_small, d_records, d_ctr);
+        hipLaunchKernelGGL(gsah_eval_kernel, dim3((nactive + EVAL_WAVES - 1u) / EVAL_WAVES), dim3(64 * EVAL_WAVES), 0, stream, d_nodes[cur], nactive, d_gbins, level,
+                           level_records, max_leaf, d_splits, d_nodes[cur ^ 1], d_small, d_records, d_ctr);
+        level_records += nactive; // (every active node took one record)
         hipLaunchKernelGGL(gsah_flag_kernel, dim3(blocks), dim3(256), 0, stream, pbox[cur], node_of[cur], n, d_nodes[cur], d_splits, d_flag);
         GSAH_TRY(hipGetLastError());
         GSAH_TRY(rocprim::exclusive_scan(d_temp, temp_bytes, d_flag, d_scan, 0u, (size_t)n, rocprim::plus<uint32_t>(), stream));
@@ -530,6 +553,8 @@ hipError_t gsah_build(const float *d_tri9, const int *d_mat, const float *d_refb
         cur ^= 1;
         levels_run = level + 1;
     }
+    // the small nodes take their records behind the levels' (which no counter counted), and count their own depth and use
+    GSAH_TRY(hipMemcpyAsync(&d_ctr->nodes, &level_records, sizeof(uint32_t), hipMemcpyHostToDevice, stream));
     if (nsmall > 0) {
         hipLaunchKernelGGL(gsah_small_kernel, dim3(nsmall), dim3(64), 0, stream, d_small, pbox[cur], pid[cur], max_leaf, tri_cost, d_records, d_ctr);
         GSAH_TRY(hipGetLastError());
@@ -541,6 +566,8 @@ hipError_t gsah_build(const float *d_tri9, const int *d_mat, const float *d_refb
     GSAH_TRY(hipMemcpyAsync(&h, d_ctr, sizeof h, hipMemcpyDeviceToHost, stream));
     GSAH_TRY(hipMemcpyAsync(above, d_records + 4 * (size_t)n, sizeof above, hipMemcpyDeviceToHost, stream));
     GSAH_TRY(hipStreamSynchronize(stream));
+    h.used += level_records;                               // (the levels' records are all in use)
+    h.depth = h.depth > levels_run ? h.depth : levels_run; // (level l holds the nodes of depth l + 1)
     if (h.nodes > 0) { // breadth-first numbering; the tier-A buffers are free by now: keys / values of the sort live in them
         if (h.nodes >= n || h.used > h.nodes) { cleanup(); return hipErrorUnknown; }
         uint32_t *key_in = d_flag, *key_out = d_scan, *val_in = pid[cur ^ 1], *val_out = (uint32_t *)node_of[0], *renum = (uint32_t *)node_of[1];
