@@ -277,7 +277,7 @@ struct Tuning {
 // on one stream are ordered and share a set; calls on different streams get different sets, so their kernels may overlap
 // (the next frame fills the GPU while this one's last waves drain) and two host-pointer renders never share staging.
 // How a frame with sample chunks is rendered: through slabs and a second kernel, or through the waves' rings (crt_kernels.h: CM_*).
-struct ChunkPlan { uint32_t mode = CM_WHOLE, ring_slots = 0; size_t bytes = 0; };
+struct ChunkPlan { uint32_t mode = CM_WHOLE, ring_slots = 0, fetch_units = 0, ring_batch = 0; size_t bytes = 0; }; // (fetch_units / ring_batch 0: the tuning's, or the launcher's defaults)
 
 struct StreamScratch {
     hipStream_t stream = nullptr; bool used = false, recorded = false; uint64_t last_use = 0;
@@ -932,7 +932,18 @@ static ChunkPlan plan_chunks(const crt_scene *s, const DeviceScene &d, const crt
     ra.chunk_mode = CM_RING;
     const uint32_t waves = d.cus * (uint32_t)t.waves_per_cu;
     plan.mode = CM_RING;
-    plan.ring_slots = ring_must_fit ? render_ring_slots_that_fit(ra, waves, budget) : (ra.ring_slots ? std::min(std::max(ra.ring_slots, 2u), 16u) : CRT_RING_SLOTS_DEFAULT);
+    if (ring_must_fit) { // crt_render_noalloc: what its static scratch admits (blocks of 128 units, 2..4 slots, no batching)
+        plan.ring_slots = render_ring_slots_that_fit(ra, waves, budget);
+    } else {
+        // crt_render, where memory is no object (126 MB per stream on 256 CUs at 64 spp): 8 slots of 256-unit blocks, complete blocks
+        // added up four at a time -- 8.42 ms on the headline frame against 9.43 with 4 x 128 x 1 (16 slots: 8.38;
+        // profiles/r3_v2_gpu_sah/ringsweep.txt).  An environment setting wins; very large sample counts (a block is at least
+        // one pixel's samples) take fewer slots so that the ring stays within the slab budget where it can.
+        if (t.fetch_block == 0) plan.fetch_units = ra.fetch_units = 256u;
+        plan.ring_batch = t.ring_batch ? (uint32_t)t.ring_batch : 4u;
+        plan.ring_slots = ra.ring_slots ? std::min(std::max(ra.ring_slots, 2u), 16u) : 8u;
+        while (!ra.ring_slots && plan.ring_slots > 2u && render_ring_bytes(ra, waves, plan.ring_slots) > budget) plan.ring_slots /= 2u;
+    }
     plan.bytes = plan.ring_slots ? render_ring_bytes(ra, waves, plan.ring_slots) : 0;
     return plan;
 }
@@ -951,6 +962,8 @@ static int enqueue_render(const crt_scene *s, const DeviceScene &d, const crt_ca
     if (plan.mode == CM_RING) {
         ra.ring_lo = (uint32_t)(uintptr_t)d_chunks; ra.ring_hi = (uint32_t)((uint64_t)(uintptr_t)d_chunks >> 32);
         ra.ring_slots = plan.ring_slots;
+        if (plan.fetch_units) ra.fetch_units = plan.fetch_units;
+        if (plan.ring_batch) ra.ring_batch = plan.ring_batch;
     } else if (plan.mode == CM_SLAB) d_target = d_chunks; // raw chunk sums, [pixel][chunk][3]
     HIP_TRY(hipMemsetAsync(d_counters, 0, CRT_COUNTER_BYTES, stream));
     if (ev0) HIP_TRY(hipEventRecord(ev0, stream));
