@@ -469,8 +469,10 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
     // in P_STARVED without counting as ready -- they would keep the wave in the shade phase while the walks that could complete a
     // block never advance -- and the others vote as a smaller wave.
     __shared__ uint32_t ring_block_all[W][16];
-    const uint32_t wave_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave); // (a scalar: no lane register for it)
-    uint32_t *ring_block = ring_block_all[wave_s];
+    // (the wave's index as a scalar and its row of ring_block_all are formed where they are needed -- once per block or per pass of
+    // ring sums: kept across the main loop they were two of the five scalar registers the RING kernels spilled into lane registers)
+#define CRT_WAVE_S ((uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)))
+#define CRT_RING_BLOCK (ring_block_all[CRT_WAVE_S])
     uint32_t ring_count = 0;
     uint32_t ring_state = RING ? (1u << ra.ring_slots) - 1u : 0u, ring_aux = 0;
     uint32_t stripe = home, stripes_left = CRT_WORK_STRIPES; // counter in use, counters not yet seen empty
@@ -496,16 +498,16 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
     for (uint32_t guard = 0;; guard++) {
         // sample chunks: complete blocks are added up and written out here, where few registers are live -- when ring_batch of them
         // have collected, or when the ring has no free slot left; their slots are free again and the lanes that waited may ask again
-        if (RING && __builtin_expect((ring_state >> 16) != 0u && (popc64(ring_state >> 16) >= (int)ra.ring_batch || (ring_state & 0xFFFFu) == 0u), 0)) {
+        if (RING && __builtin_expect((ring_aux & 0x80000000u) != 0u, 0)) { // (set in the shade phase when the ring's state says so)
             CRT_LAP(clk, 0);
             const RenderArgs rak = load_kernel_arg<RenderArgs>(offsetof(KernelArgsLayout, ra));
             const global_f32_ptr wring = (global_f32_ptr)(uintptr_t)((uint64_t)rak.ring_lo | (uint64_t)rak.ring_hi << 32) +
-                                         (size_t)(rak.ring_wave_base + blockIdx.x * W + wave_s) * rak.ring_slots * rak.block_units * 3u;
+                                         (size_t)(rak.ring_wave_base + blockIdx.x * W + CRT_WAVE_S) * rak.ring_slots * rak.block_units * 3u;
             const uint32_t done = ring_state >> 16;
-            finalize_ring_blocks(rak, out, wring, done, ring_block, lane);
+            finalize_ring_blocks(rak, out, wring, done, CRT_RING_BLOCK, lane);
             ring_count = (done >> lane) & 1u ? 0u : ring_count;
             ring_state = (ring_state & 0xFFFFu) | done; // done -> free
-            ring_aux &= 0xFu;                            // nobody starved
+            ring_aux &= 0xFu;                            // nobody starved, nothing to add up
             phase = phase == P_STARVED ? P_FETCH : phase;
             CRT_LAP(clk, 9);
         }
@@ -522,7 +524,7 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
             break;
         }
         if (guard >= guard_limit) { guard_tripped = true; break; }
-        const int threshold = RING ? max(threshold_all - (int)(ring_aux >> 8), 1) : threshold_all;
+        const int threshold = RING ? max(threshold_all - (int)((ring_aux >> 8) & 0x7Fu), 1) : threshold_all;
         if (nready >= threshold || nwalk == 0) {
             // ================================ phase A ================================
             if constexpr (COUNT_WORK) { if (lane == 0) { wc[0]++; wc[1] += nready; } }
@@ -585,7 +587,7 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
                 if (ring_mode) {
                     // q = ring slot << 16 | index of the unit in its block; the unit's raw sum goes to the wave's ring
                     const global_f32_ptr wring = (global_f32_ptr)(uintptr_t)((uint64_t)rak.ring_lo | (uint64_t)rak.ring_hi << 32) +
-                                                 (size_t)(rak.ring_wave_base + blockIdx.x * W + wave_s) * rak.ring_slots * block_units * 3u;
+                                                 (size_t)(rak.ring_wave_base + blockIdx.x * W + CRT_WAVE_S) * rak.ring_slots * block_units * 3u;
                     const bool done = fetching && q != NO_PIXEL;
                     if (done && pixel != NO_PIXEL) { // (pixel == NO_PIXEL: a unit outside the image, only counted)
                         const global_f32_ptr dst = wring + ((q >> 16) * block_units + (q & 0xFFFFu)) * 3u;
@@ -644,7 +646,7 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
                     if (ring_mode && fresh_units) { // the new block takes a free ring slot (its count is 0)
                         fresh_rs = (uint32_t)__builtin_ctz(ring_state);
                         ring_state &= ring_state - 1u;
-                        ring_block[fresh_rs] = fresh_block;
+                        CRT_RING_BLOCK[fresh_rs] = fresh_block;
                     }
                 }
                 // the lane's unit: index k in the wave's current block, or in the fresh one
@@ -660,6 +662,10 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
                         ring_aux = (ring_aux & ~0xFu) | fresh_rs;
                     } else blk_next = blk_end;
                 } else blk_next += n_need;
+                if (ring_mode) { // complete blocks are added up (top of the loop) once ring_batch of them wait, or when no slot is free for a new block
+                    const bool flush = (ring_state >> 16) != 0u && (popc64(ring_state >> 16) >= (int)ra.ring_batch || (ring_state & 0xFFFFu) == 0u);
+                    ring_aux = flush ? ring_aux | 0x80000000u : ring_aux;
+                }
                 const bool exhausted = stripes_left == 0;
                 if (ring_mode && !exhausted && n_need > left + fresh_units) {
                     ring_aux += (n_need - left - fresh_units) << 8; // lanes that will wait for a ring slot
@@ -815,10 +821,12 @@ __device__ __forceinline__ void render_body(const SceneView &sc, const CameraPOD
     if (RING && (ring_state >> 16) != 0u) { // the complete blocks that were still collecting
         const RenderArgs rak = load_kernel_arg<RenderArgs>(offsetof(KernelArgsLayout, ra));
         const global_f32_ptr wring = (global_f32_ptr)(uintptr_t)((uint64_t)rak.ring_lo | (uint64_t)rak.ring_hi << 32) +
-                                     (size_t)(rak.ring_wave_base + blockIdx.x * W + wave_s) * rak.ring_slots * rak.block_units * 3u;
-        finalize_ring_blocks(rak, out, wring, ring_state >> 16, ring_block, lane);
+                                     (size_t)(rak.ring_wave_base + blockIdx.x * W + CRT_WAVE_S) * rak.ring_slots * rak.block_units * 3u;
+        finalize_ring_blocks(rak, out, wring, ring_state >> 16, CRT_RING_BLOCK, lane);
     }
     if (RING && __ballot(phase == P_STARVED)) guard_tripped = true; // (see the loop's exit)
+#undef CRT_RING_BLOCK
+#undef CRT_WAVE_S
     uint32_t refolds = 0;
     if constexpr (COUNT_WORK) refolds = wave_sum(cnt.refolds);
     if (lane == 0) {
