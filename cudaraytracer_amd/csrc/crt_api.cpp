@@ -411,6 +411,10 @@ struct crt_scene {
     std::vector<Shade> shades; // materials joined with their textures (device record)
     std::vector<q4> normals;   // per triangle slot: unit normal + primitive id (crt_traverse.h: triangle_normal)
     uint32_t builder = 0, binary_depth = 0; float build_ms = 0.0f, sah_cost = 0.0f;
+    // A tree built on the device leaves its slots and normals THERE (no host copy: bvh.tris / normals stay empty, nslots counts):
+    // the replica on that device adopts the two buffers, further replicas copy from that one device to device.
+    struct Built { int device = -1; void *d_tris = nullptr, *d_normals = nullptr; } built;
+    size_t nslots = 0;
     std::vector<Sphere> flat_spheres; // the spheres that are tested before the walk (the others are slots of the tree)
     bool sphere_slots = false;        // some spheres went into the tree
     Tuning tuning;
@@ -419,9 +423,19 @@ struct crt_scene {
     std::mutex mutex;                 // crt_render's bookkeeping (scratch sets, staging): calls on different streams may come from different threads
 
     void release_multi();
+    void release_built()
+    {
+        if (built.d_tris || built.d_normals) {
+            if (built.device >= 0) (void)hipSetDevice(built.device);
+            if (built.d_tris) (void)hipFree(built.d_tris);
+            if (built.d_normals) (void)hipFree(built.d_normals);
+        }
+        built = Built();
+    }
     void release_device()
     {
         release_multi();
+        release_built();
         for (DeviceScene &d : dev) d.release();
         dev.clear();
         device = -1;
@@ -561,13 +575,18 @@ static bool commit_gpu_lbvh(crt_scene *s, int device, uint32_t max_leaf, uint32_
         }
     }
     LbvhOutput out;
+    out.keep_on_device = tree_kind == LBVH_TREE_SAH && !getenv("CRT_BUILD_HOST_COPIES"); // (the debugging switch brings everything to the host as before)
     clk.lap("pack triangles");
     if (lbvh_build(tri9.data(), mat.data(), (uint32_t)n, su, !sph.empty(), sph.data(), (uint32_t)sph.size(), max_leaf, tree_kind, out, nullptr) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
     clk.lap("device build + transfers");
-    if (out.depth > CRT_STACK_DEPTH) return false; // long runs of equal codes: the host builder bounds the depth
+    if (out.depth > CRT_STACK_DEPTH) { // long runs of equal codes: the host builder bounds the depth
+        if (out.d_slots) (void)hipFree(out.d_slots);
+        if (out.d_normals) (void)hipFree(out.d_normals);
+        return false;
+    }
     // ranks: triangles from the device; a sphere follows every triangle with a code <= its own (stable sort, triangles
     // first in the reference's list) and the spheres that sort before it
     s->rank.assign(n + s->spheres.size(), 0);
@@ -583,6 +602,8 @@ static bool commit_gpu_lbvh(crt_scene *s, int device, uint32_t max_leaf, uint32_
     s->normals.swap(out.normals); // (SAH builder: made on the device with the slots; else empty)
     s->bvh.nodes.swap(out.nodes);
     s->bvh.tris.swap(out.slots);
+    s->nslots = n;
+    s->built.device = device; s->built.d_tris = out.d_slots; s->built.d_normals = out.d_normals;
     s->bvh.root_ref = out.root_ref; s->bvh.root_box = out.root_box; s->bvh.depth = out.depth; s->bvh.max_leaf = max_leaf;
     s->builder = tree_kind == LBVH_TREE_SAH ? 2u : 1u; s->build_ms = out.build_ms;
     clk.lap("sphere ranks + renumbering");
@@ -700,8 +721,9 @@ static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
 
     // the unit normal of every triangle slot, with the operations the hit record uses (sphere slots: unused)
     {
-        const size_t nslots = s->bvh.tris.size() / 3;
-        const bool have = gpu_built && s->normals.size() == nslots && nslots > 0;
+        if (!gpu_built) s->nslots = s->bvh.tris.size() / 3;
+        const size_t nslots = s->nslots;
+        const bool have = gpu_built && (s->built.d_normals || (s->normals.size() == nslots && nslots > 0));
         if (!have) s->normals.resize(nslots);
         for (size_t k = 0; k < nslots && !have; k++) {
             const q4 *tp = &s->bvh.tris[3 * k];
@@ -736,10 +758,26 @@ static int upload_replica(crt_scene *s, DeviceScene &d, int device)
     d.device = device;
     int rc;
     if ((rc = upload(&d.d_nodes, s->bvh.nodes))) return rc;
-    if ((rc = upload(&d.d_tris, s->bvh.tris))) return rc;
     if ((rc = upload(&d.d_spheres, s->flat_spheres))) return rc;
     if ((rc = upload(&d.d_shades, s->shades))) return rc;
-    if ((rc = upload(&d.d_normals, s->normals))) return rc;
+    if (s->built.d_tris && s->built.device == device) { // the builder's own buffers, where it left them
+        d.d_tris = s->built.d_tris; d.d_normals = s->built.d_normals;
+        s->built = crt_scene::Built();
+    } else if (s->bvh.tris.empty() && s->nslots && !s->dev.empty() && s->dev[0].d_tris && &d != &s->dev[0]) { // no host copy: from the first replica
+        const size_t tb = s->nslots * 3 * sizeof(q4), nb = s->nslots * sizeof(q4);
+        HIP_TRY(hipMalloc(&d.d_tris, tb));
+        HIP_TRY(hipMalloc(&d.d_normals, nb));
+        if (s->dev[0].device == device) {
+            HIP_TRY(hipMemcpy(d.d_tris, s->dev[0].d_tris, tb, hipMemcpyDeviceToDevice));
+            HIP_TRY(hipMemcpy(d.d_normals, s->dev[0].d_normals, nb, hipMemcpyDeviceToDevice));
+        } else {
+            HIP_TRY(hipMemcpyPeer(d.d_tris, device, s->dev[0].d_tris, s->dev[0].device, tb));
+            HIP_TRY(hipMemcpyPeer(d.d_normals, device, s->dev[0].d_normals, s->dev[0].device, nb));
+        }
+    } else {
+        if ((rc = upload(&d.d_tris, s->bvh.tris))) return rc;
+        if ((rc = upload(&d.d_normals, s->normals))) return rc;
+    }
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     d.cus = (uint32_t)prop.multiProcessorCount;
@@ -751,7 +789,7 @@ static int upload_replica(crt_scene *s, DeviceScene &d, int device)
     SceneView &v = d.view;
     v.nodes = (const q4 *)d.d_nodes; v.tris = (const q4 *)d.d_tris; v.spheres = (const Sphere *)d.d_spheres;
     v.shades = (const Shade *)d.d_shades; v.normals = (const q4 *)d.d_normals;
-    v.root_ref = s->bvh.root_ref; v.wide = s->bvh.wide ? 1u : 0u; v.nnodes = (uint32_t)(s->bvh.nodes.size() / (s->bvh.wide ? 8 : 4)); v.ntris = (uint32_t)(s->bvh.tris.size() / 3);
+    v.root_ref = s->bvh.root_ref; v.wide = s->bvh.wide ? 1u : 0u; v.nnodes = (uint32_t)(s->bvh.nodes.size() / (s->bvh.wide ? 8 : 4)); v.ntris = (uint32_t)s->nslots;
     v.nspheres = (uint32_t)s->flat_spheres.size(); v.sphere_slots = s->sphere_slots ? 1u : 0u;
     v.root_min = s->bvh.root_box.mn; v.root_max = s->bvh.root_box.mx;
     return CRT_OK;
@@ -788,7 +826,7 @@ extern "C" int crt_scene_get_info(const crt_scene *s, crt_scene_info *info)
     info->num_materials = (uint32_t)s->mats.size(); info->num_textures = (uint32_t)s->texs.size();
     info->num_nodes = (uint32_t)(s->bvh.nodes.size() / (s->bvh.wide ? 8 : 4)); info->bvh_depth = s->bvh.depth; info->max_leaf_size = s->bvh.max_leaf;
     info->device = s->committed ? (uint32_t)s->device : UINT32_MAX;
-    info->node_bytes = s->bvh.nodes.size() * sizeof(q4); info->triangle_bytes = s->bvh.tris.size() * sizeof(q4);
+    info->node_bytes = s->bvh.nodes.size() * sizeof(q4); info->triangle_bytes = s->nslots * 3 * sizeof(q4);
     info->sphere_bytes = s->flat_spheres.size() * sizeof(Sphere);
     info->bounds_min[0] = s->bvh.root_box.mn.x; info->bounds_min[1] = s->bvh.root_box.mn.y; info->bounds_min[2] = s->bvh.root_box.mn.z;
     info->builder = s->builder; info->build_ms = s->build_ms; info->node_width = s->bvh.wide ? 4u : 2u; info->binary_depth = s->binary_depth; info->sah_cost = s->sah_cost;

@@ -17,6 +17,10 @@ struct LbvhOutput {
     std::vector<q4> slots;              // 3 per triangle, in sorted (rank) order
     std::vector<q4> normals;            // per slot (SAH tree only; else empty: the host computes them)
     bool breadth_first = false;         // nodes are numbered breadth first already (SAH tree)
+    // in: keep the slots and normals of a SAH tree on the device instead of bringing them to the host (`slots` / `normals` stay
+    // empty); out: the two buffers, the caller's to hipFree (or to render from: they are what a replica on that device holds)
+    bool keep_on_device = false;
+    void *d_slots = nullptr, *d_normals = nullptr;
     std::vector<uint32_t> rank_of_tri;  // global rank of triangle i
     std::vector<uint32_t> sorted_codes; // the triangles' codes in sorted order (for the spheres' ranks)
     LbvhSphereCodes sphere_codes{};

@@ -400,16 +400,23 @@ hipError_t lbvh_build(const float *h_tri9, const int *h_mat, uint32_t n, const B
     out.scene_box = scene;
     out.sphere_codes = sc;
     out.rank_of_tri.resize(n);
-    out.slots.resize((size_t)n * 3);
+    const bool keep = out.keep_on_device && tree_kind == LBVH_TREE_SAH;
+    out.slots.clear();
     LBVH_TRY(hipMemcpyAsync(out.rank_of_tri.data(), d_rank, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    LBVH_TRY(hipMemcpyAsync(out.slots.data(), d_slots, (size_t)n * 3 * sizeof(q4), hipMemcpyDeviceToHost, stream));
+    if (!keep) {
+        out.slots.resize((size_t)n * 3);
+        LBVH_TRY(hipMemcpyAsync(out.slots.data(), d_slots, (size_t)n * 3 * sizeof(q4), hipMemcpyDeviceToHost, stream));
+    }
     Box6 rootbox{};
     uint32_t depth = 0;
     if (tree_kind == LBVH_TREE_SAH) {
         out.nodes.resize((size_t)sah.num_records * 4);
         if (sah.num_records) LBVH_TRY(hipMemcpyAsync(out.nodes.data(), d_nodes_bf, (size_t)sah.num_records * 4 * sizeof(q4), hipMemcpyDeviceToHost, stream));
-        out.normals.resize(n);
-        LBVH_TRY(hipMemcpyAsync(out.normals.data(), d_normals, (size_t)n * sizeof(q4), hipMemcpyDeviceToHost, stream));
+        out.normals.clear();
+        if (!keep) {
+            out.normals.resize(n);
+            LBVH_TRY(hipMemcpyAsync(out.normals.data(), d_normals, (size_t)n * sizeof(q4), hipMemcpyDeviceToHost, stream));
+        }
         out.breadth_first = true;
         out.root_ref = sah.root_ref;
         LBVH_TRY(hipStreamSynchronize(stream));
@@ -434,6 +441,8 @@ hipError_t lbvh_build(const float *h_tri9, const int *h_mat, uint32_t n, const B
     float ms = 0.0f;
     LBVH_TRY(hipEventElapsedTime(&ms, e0, e1));
     out.build_ms = ms;
+    out.d_slots = out.d_normals = nullptr;
+    if (keep) { out.d_slots = d_slots; out.d_normals = d_normals; d_slots = nullptr; d_normals = nullptr; } // (the caller's from here on)
     cleanup();
     return hipSuccess;
 }

@@ -55,6 +55,39 @@ def _commit(scenes, capi, desc, devices):
 
 
 @pytest.mark.gpu
+def test_replicas_of_a_device_built_scene_copy_from_the_first(capi, scenes):
+    """A scene large enough for crt_scene_commit_devices to build its tree on devices[0] (crt_gsah.hip) has no host copy of its
+    slots and normals: rank 0 adopts the builder's buffers, the other ranks' replicas are device-to-device copies of them.
+    Three logical ranks on device 0 render the frame of the same scene committed through the host builder, bit for bit."""
+    n = 36000
+    rng = np.random.default_rng(11)
+    d = scenes._base()
+    d["materials"].append(dict(type=capi.MAT_LAMBERTIAN, rgb=(0.7, 0.3, 0.16), param=0.0, texture=None))
+    scenes._add_ref_spheres(d)
+    c = rng.uniform(-2.0, 2.0, size=(n, 1, 3)).astype(np.float32) * np.array([1.0, 0.4, 1.0], np.float32) + np.array([0.0, 1.2, 0.0], np.float32)
+    v = (c + rng.uniform(-0.05, 0.05, size=(n, 3, 3)).astype(np.float32)).reshape(3 * n, 3)
+    d["meshes"].append(dict(vertices=np.ascontiguousarray(v), indices=np.arange(3 * n, dtype=np.uint32).reshape(n, 3), material=0))
+    s = capi.Scene()
+    for m in d["materials"]:
+        s.add_material(m["type"], m["rgb"], m["param"], capi.NO_TEXTURE)
+    for me in d["meshes"]:
+        s.add_mesh(me["vertices"], me["indices"], me["material"])
+    for sp in d["spheres"]:
+        s.add_sphere(sp["center"], sp["radius"], sp["material"])
+    s.commit_devices([0, 0, 0], capi.BUILD_AUTO)
+    host = scenes.build(d, 0, 0)
+    assert s.info().builder == 2 and host.info().builder == 0 and s.info().triangle_bytes == 48 * n
+    W, H, spp = 160, 90, 3
+    _, cam = scenes.make_camera(W)
+    want, want_ids, st0 = host.render(cam, W, H, spp, want_ids=True)
+    for mode in (capi.MULTI_TILE, capi.MULTI_SAMPLE):
+        rgb, ids, st = s.render(cam, W, H, spp, want_ids=True, multi=mode)
+        assert np.array_equal(ids, want_ids) and st.rays == st0.rays
+        assert np.array_equal(rgb, want) if mode == capi.MULTI_TILE else np.allclose(rgb, want, rtol=3e-7, atol=1e-7)
+    assert (want_ids >= 0).any() and ((want_ids >= 0) & (want_ids < n)).any()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ranks,threads", [(1, "1"), (2, "0"), (3, "1"), (8, "0"), (8, "1")])
 def test_multi_tile_mode_is_bitwise_the_single_device_frame(oracle, capi, scenes, monkeypatch, ranks, threads):
     monkeypatch.setenv("CRT_MULTI_THREADS", threads)             # 1: every rank's part of a frame is enqueued by a thread of its own
