@@ -148,6 +148,9 @@ __device__ __forceinline__ bool slot_pixel(const RenderArgs &ra, uint32_t slot, 
 // is the sequential sum bit for bit -- and writes the finished pixels.  One lane per (pixel of the block, colour channel): the
 // three chains of a pixel are independent, a chain is n dependent additions.  No slabs in HBM, no second kernel.
 typedef __attribute__((address_space(1))) float *global_f32_ptr;
+#ifndef CRT_RING_LOADS_IN_FLIGHT
+#define CRT_RING_LOADS_IN_FLIGHT 32
+#endif
 // `done`: the ring slots whose blocks are complete (at least one).  Their pixels' chains are dealt to the lanes together -- the
 // pass costs the same instructions whether 6 or 60 lanes take part, so the caller lets complete blocks collect (RenderArgs.ring_batch).
 __device__ __forceinline__ void finalize_ring_blocks(const RenderArgs &ra, float *__restrict__ out, global_f32_ptr wring, uint32_t done,
@@ -172,6 +175,17 @@ __device__ __forceinline__ void finalize_ring_blocks(const RenderArgs &ra, float
 #else
             if (ra.chunk_spp == 1u) { // one sample per chunk: the reference's own loop (a chunk sum 0 + s is s: the sum so far is never -0)
                 uint32_t k = 0;
+#if CRT_RING_LOADS_IN_FLIGHT > 8
+                // long chains (hundreds of samples per pixel) wait for their loads, not for their additions: more of them in flight
+                // (4K x 1024 spp: 521 ms with 32, 528 with 16, 538 with 8; at 64 spp the short form is as fast and holds fewer registers)
+                for (; n >= 128u && k + (uint32_t)CRT_RING_LOADS_IN_FLIGHT <= n; k += (uint32_t)CRT_RING_LOADS_IN_FLIGHT, src += 3 * CRT_RING_LOADS_IN_FLIGHT) {
+                    float v[CRT_RING_LOADS_IN_FLIGHT];
+#pragma unroll
+                    for (int j = 0; j < CRT_RING_LOADS_IN_FLIGHT; j++) v[j] = src[3 * j];
+#pragma unroll
+                    for (int j = 0; j < CRT_RING_LOADS_IN_FLIGHT; j++) acc = acc + v[j];
+                }
+#endif
                 for (; k + 8u <= n; k += 8u, src += 24) { // eight loads in flight, their offsets in the instructions
                     const float s0 = src[0], s1 = src[3], s2 = src[6], s3 = src[9], s4 = src[12], s5 = src[15], s6 = src[18], s7 = src[21];
                     acc = acc + s0; acc = acc + s1; acc = acc + s2; acc = acc + s3; acc = acc + s4; acc = acc + s5; acc = acc + s6; acc = acc + s7;
