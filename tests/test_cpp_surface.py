@@ -49,6 +49,26 @@ def test_reference_style_driver_matches_oracle(oracle, scenes, tmp_path, spp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("builder", ["gpusah", "lbvh", "host"])
+def test_reference_style_driver_with_each_builder(tmp_path, builder):
+    """CRT_BUILDER through the C++ surface (Scene::launch_triangles_scene -> crt_scene_commit): whoever builds the tree, the
+    driver writes the same file, byte for byte."""
+    model = os.path.join(helpers.REPO, "models", "cats.obj")
+    outs = []
+    for env_builder in (None, builder):
+        d = tmp_path / (env_builder or "default")
+        d.mkdir()
+        env = dict(os.environ)
+        env.pop("CRT_BUILDER", None)
+        if env_builder:
+            env["CRT_BUILDER"] = env_builder
+        r = subprocess.run([DEMO, model, "192", "108", "3"], cwd=d, capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stderr
+        outs.append(open(d / "output.ppm", "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) > 192 * 108 * 3
+
+
+@pytest.mark.gpu
 def test_reference_style_driver_sphere_scene(tmp_path):
     """launch_random_scene_kernel (scene.h:197-235) through the C++ surface: 488 spheres, PNG out.  The C++ generator's
     numbers are its own, so the check is on the frame's content, not against the oracle (tests/test_gpu.py does that for

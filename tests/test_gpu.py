@@ -490,6 +490,20 @@ def test_thousands_of_exactly_coincident_triangles(oracle, scenes, capi, node_ca
     assert ((ids >= 0) & (ids < 3 * copies)).sum() > 100 and st.tie_refolds > 100 and seconds < 5.0
 
 
+def test_gpu_sah_builder_with_host_copies(oracle, scenes, capi, monkeypatch):
+    """CRT_BUILD_HOST_COPIES=1 (a debugging switch): slots and normals come down to the host and go up again as before the
+    replica adopted the builder's buffers; same scene, same frame."""
+    desc = scenes.cats()
+    adopted = scenes.build(desc, 0, capi.BUILD_GPU_SAH)
+    monkeypatch.setenv("CRT_BUILD_HOST_COPIES", "1")
+    copied = scenes.build(desc, 0, capi.BUILD_GPU_SAH)
+    monkeypatch.delenv("CRT_BUILD_HOST_COPIES")
+    assert adopted.info().builder == 2 and copied.info().builder == 2 and adopted.info().triangle_bytes == copied.info().triangle_bytes
+    _, cam = scenes.make_camera(160)
+    a, b = adopted.render(cam, 160, 90, 2, want_ids=True), copied.render(cam, 160, 90, 2, want_ids=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2].rays == b[2].rays
+
+
 @pytest.mark.parametrize("n", [40, 5000])
 def test_gpu_sah_builder_depth_bound_on_degenerate_input(oracle, scenes, capi, n):
     """Nested slivers: the SAH plane peels one sliver off at a time until the depth bound forces medians -- in the one-wave
