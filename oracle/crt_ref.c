@@ -521,8 +521,8 @@ int ref_scene_commit(ref_scene *s)
     free(s->list); free(s->morton); free(s->indices); free(s->rank); free(s->nodes);
     s->size = n;
     s->list = (prim_t *)malloc((size_t)n * sizeof(prim_t));
-    memcpy(s->list, s->tris, (size_t)s->ntris * sizeof(prim_t));
-    memcpy(s->list + s->ntris, s->spheres, (size_t)s->nspheres * sizeof(prim_t));
+    if (s->ntris) memcpy(s->list, s->tris, (size_t)s->ntris * sizeof(prim_t)); /* (a scene without triangles has no array to copy from) */
+    if (s->nspheres) memcpy(s->list + s->ntris, s->spheres, (size_t)s->nspheres * sizeof(prim_t));
     /* scene.h:167-170 scene bbox = fold of unions in list order */
     s->scene_bbox = s->list[0].bbox;
     for (uint32_t i = 1; i < n; i++) s->scene_bbox = aabb_union(s->scene_bbox, s->list[i].bbox);
