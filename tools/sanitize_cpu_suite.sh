@@ -16,3 +16,9 @@ ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$(gcc -print-fil
 echo "== back to the normal builds"
 make -s -C tests/hostsim -B
 make -s -C oracle -B
+# The library's own host code (crt_api.cpp, crt_bvh.cpp, the host halves of the .hip files) under UBSan on the GPU box -- run once in
+# round 3, all 190 GPU tests passed:
+#   g++ ... -fsanitize=undefined -fno-sanitize=vptr -fno-sanitize-recover=undefined -c crt_api.cpp crt_bvh.cpp
+#   hipcc ... -Xarch_host -fsanitize=undefined -Xarch_host -fno-sanitize=function,vptr -Xarch_host -fno-sanitize-recover=undefined -c *.hip
+#   hipcc -shared ... *.o $(gcc -print-file-name=libubsan.so) -o ablib/lib_ubsan.so
+#   CRT_LIB=$PWD/ablib/lib_ubsan.so python -m pytest tests -m gpu     (via gpurun)
