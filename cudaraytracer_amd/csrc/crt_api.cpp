@@ -243,7 +243,8 @@ namespace crt_detail {
 struct Tuning {
     int kernel = 0;            // CRT_KERNEL: 0 render_kernel (pixel per lane), 1 render_pool_kernel (whole-pixel frames only)
     int pool_refill = 16;      // CRT_POOL_REFILL: pool kernel, free lanes that end a run of walk steps
-    int sched_threshold = 44;  // CRT_SCHED_THRESHOLD: lanes that must wait for the shade phase before it runs
+    int sched_threshold = 0;   // CRT_SCHED_THRESHOLD: lanes that must wait for the shade phase before it runs; 0 = by scene: 44, or 52 for scenes
+                               // whose tree holds sphere slots (scene.h:53-90: 10.65 against 10.85 ms; triangle scenes, rings and the grid: 44 is the optimum)
     int fetch_block = 0;       // CRT_FETCH_BLOCK: work units per trip to a block counter (a power of two, 64..65536); 0: chosen per frame
     int node_cache = 1;        // CRT_NODE_CACHE: 0 single waves, 1 chosen per frame, 2 four-wave workgroups with an LDS copy of the tree's top, 3 whole tree in one 16-wave workgroup, 4 16 + 4 wave split (crt_kernels.h)
     int stripe_bands = 1;      // CRT_STRIPE_BANDS: each block counter owns a contiguous band of the frame
@@ -258,7 +259,7 @@ struct Tuning {
     {
         kernel = get_env_int("CRT_KERNEL", 0) == 1 ? 1 : 0;
         pool_refill = std::min(std::max(get_env_int("CRT_POOL_REFILL", 16), 1), 63);
-        sched_threshold = std::min(std::max(get_env_int("CRT_SCHED_THRESHOLD", 44), 1), 64);
+        sched_threshold = std::min(std::max(get_env_int("CRT_SCHED_THRESHOLD", 0), 0), 64);
         node_cache = std::min(std::max(get_env_int("CRT_NODE_CACHE", 1), 0), 4);
         fetch_block = std::min(std::max(get_env_int("CRT_FETCH_BLOCK", 0), 0), 65536);
         stripe_bands = get_env_int("CRT_STRIPE_BANDS", 1) ? 1 : 0;
@@ -940,7 +941,7 @@ static RenderArgs render_args(const crt_scene *s, const crt_render_params *p, ui
     // the pool kernel has no sample chunks: chosen here with launch_render's own condition, and the threshold with it
     const bool pool = t.kernel == 1 && chunks == 1 && pool_kernel_built();
     ra.kernel = pool ? (uint32_t)RK_POOL : (uint32_t)RK_LANES;
-    ra.sched_threshold = (uint32_t)(pool ? t.pool_refill : t.sched_threshold);
+    ra.sched_threshold = (uint32_t)(pool ? t.pool_refill : t.sched_threshold ? t.sched_threshold : s->sphere_slots ? 52 : 44);
     ra.bvh_depth = s->bvh.depth;
     ra.node_cache = (uint32_t)t.node_cache;
     ra.fetch_units = (uint32_t)t.fetch_block;         // 0 = launch_render's rule
