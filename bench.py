@@ -150,6 +150,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if os.environ.get("CRT_BENCH_WATCHDOG"):  # where every thread stands after so many seconds (rehearsals of the N-rank path)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["CRT_BENCH_WATCHDOG"]), repeat=False, file=sys.stderr)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -158,11 +161,21 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py: no HIP device visible; the hot path has no CPU fallback")
+    # Rehearsal on a one-GPU box (not a measurement): CRT_BENCH_SHARE_DEVICE=1 puts every rank on device 0 and
+    # CRT_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device); the N-rank code path -- launch, tile deal,
+    # pipelined gather / reduce on the side streams, barrier, max over ranks, the JSON line -- then runs as on an 8-GPU node.
+    share = os.environ.get("CRT_BENCH_SHARE_DEVICE") == "1"
+    backend = os.environ.get("CRT_BENCH_BACKEND", "nccl")
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     builder, W, H, spp, depth, cam_over = WORKLOADS[args.workload]
     if args.spp:
@@ -259,7 +272,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s %dx%d %dspp depth %d (models/%s + ground + emissive sphere, seed %d)" %
                        (args.workload, W, H, spp, depth, {"cats": "cats.obj", "random_spheres": "no mesh"}.get(builder, "cat.obj"), seed),
-                       "partition": "%s x%d" % (args.mode, world), "frames_in_flight": frame.slots.in_flight, "sample_chunks": used_chunks,
+                       "partition": "%s x%d%s" % (args.mode, world, " (REHEARSAL: ranks share device 0 over %s, not a measurement)" % backend if share else ""), "frames_in_flight": frame.slots.in_flight, "sample_chunks": used_chunks,
                        "image": image_note(used_chunks, spp if args.mode == "tile" else spp // world, args.mode == "sample" and world > 1),
                        "triangles": info.num_triangles, "bvh_nodes": info.num_nodes, "bvh_depth": info.bvh_depth, "bvh_node_width": info.node_width,
                        "rays_per_frame": int(rays_frame), "device_cus": cus},

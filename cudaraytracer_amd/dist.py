@@ -11,6 +11,7 @@ The reference is single-GPU.  Pixels are independent, the scene is replicated, a
 torch is plumbing here (buffers, streams, the collective); rendering and the epilogues are the HIP library's.
 """
 import contextlib
+import os
 
 import torch
 import torch.distributed as dist
@@ -26,6 +27,18 @@ def _device_untile(compact_all, width, height, world, frame):
 def _device_finalize(accum, width, height, total_spp, frame):
     capi.finalize(accum.data_ptr(), width, height, total_spp, frame.data_ptr(), accum.device.index,
                   torch.cuda.current_stream(accum.device).cuda_stream)
+
+
+def _gloo_on_gpu_guard(slots):
+    """gloo on device tensors (only used to rehearse the N-rank path with all ranks on ONE GPU, where RCCL refuses to run:
+    bench.py, CRT_BENCH_BACKEND=gloo): ProcessGroupGloo stages device tensors through streams of torch's HIGH-PRIORITY pool, and
+    a high-priority stream that waits for an event behind the persistent render kernel is the configuration of the hang
+    DESIGN.md section 5 describes (reproduced here in 2 ranks x 3 frames, every time, with and without the two-launch frame,
+    with 8 or 24 hardware queues; it does not happen when the render has finished before the collective is issued).  So the
+    rehearsal waits for the render first: it exercises the dealing, the collectives, the epilogues and the bookkeeping, not
+    the overlap.  RCCL (the real path) runs at normal priority and is not touched by this."""
+    if slots.gpu and dist.is_initialized() and dist.get_backend() == "gloo":
+        torch.cuda.synchronize(slots.device)
 
 
 class _Slots:
@@ -147,6 +160,7 @@ class TileFrame:
         slot, st = self._current if self._current is not None else (self.slots.slot, self.slots.render_stream())
         self._current = None
         if self.collective:
+            _gloo_on_gpu_guard(self.slots)
             with self.slots.on(st):  # the collective's stream waits for the render stream up to here
                 work = dist.all_gather_into_tensor(self._all[slot], self._local[slot], async_op=True)
             ep = self.slots.epilogue
@@ -214,6 +228,7 @@ class SampleFrame:
         ep = self.slots.epilogue if self.slots.epilogue is not None else st
         work = None
         if self.world > 1:
+            _gloo_on_gpu_guard(self.slots)
             with self.slots.on(st):
                 work = dist.reduce(self._accum[slot], dst=0, op=dist.ReduceOp.SUM, async_op=True)
         with self.slots.on(ep):

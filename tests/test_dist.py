@@ -118,3 +118,37 @@ def test_frame_assembly_over_gloo(oracle, scenes, hostsim, tmp_path, mode, world
                 assert np.array_equal(np.load(tmp_path / ("first_%s_%d.npy" % (mode, r))), fb7)
         else:
             assert np.allclose(np.load(tmp_path / ("first_%s_0.npy" % mode)), fb7, rtol=3e-7, atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,world", [("tile", 2), ("tile", 3), ("sample", 2)])
+def test_ranks_sharing_one_gpu_over_gloo(mode, world):
+    """The N-rank path with the real kernels: `world` processes on GPU 0 (RCCL refuses that, gloo does not), each rendering its
+    tiles / samples through the library, the frame assembled by dist.py.  dist.py waits for the render before a gloo collective
+    on device tensors (see _gloo_on_gpu_guard), so this covers the dealing, the collectives and the epilogues, not the overlap."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(here, "dist_gpu_rehearsal.py"), mode],
+                       capture_output=True, text=True, env=env, timeout=110)
+    assert r.returncode == 0 and "REHEARSAL OK %s %d" % (mode, world) in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_bench_rehearsal_two_ranks_on_one_gpu():
+    """bench.py --gpus 2 as the driver launches it, with both ranks on GPU 0 over gloo (CRT_BENCH_SHARE_DEVICE / CRT_BENCH_BACKEND):
+    one JSON line from rank 0, n_gpus 2, and the whole frame's ray count (the two ranks' tiles add up to it)."""
+    import json
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", CRT_BENCH_SHARE_DEVICE="1", CRT_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=110, cwd=repo)
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rays_per_frame"] == 293762168 and "REHEARSAL" in d["config"]["partition"] and d["value"] > 0
