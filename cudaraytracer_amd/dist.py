@@ -37,7 +37,7 @@ def _gloo_on_gpu_guard(slots):
     with 8 or 24 hardware queues; it does not happen when the render has finished before the collective is issued).  So the
     rehearsal waits for the render first: it exercises the dealing, the collectives, the epilogues and the bookkeeping, not
     the overlap.  RCCL (the real path) runs at normal priority and is not touched by this."""
-    if slots.gpu and dist.is_initialized() and dist.get_backend() == "gloo":
+    if slots.gpu and dist.is_initialized() and dist.get_backend() == "gloo" and not os.environ.get("CRT_DIST_NO_GUARD"):  # (the switch: to study the hang)
         torch.cuda.synchronize(slots.device)
 
 
