@@ -517,7 +517,7 @@ extern "C" int crt_scene_add_sphere(crt_scene *s, const float center[3], float r
     HostSphere sp;
     sp.center = mk3(center[0], center[1], center[2]);
     sp.radius_arg = radius;
-    sp.radius = 0.0f > radius ? 0.0f : radius; // sphere.h:11 std::max(0.0f, radius)
+    sp.radius = sphere_radius(radius); // sphere.h:11 std::max(0.0f, radius)
     sp.material = (int)material_id;
     s->spheres.push_back(sp);
     s->committed = false; s->prepared = false;
@@ -678,8 +678,8 @@ static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
             tree_spheres.push_back(BvhSphere{ sp, id, rank });
         } else {
             Sphere o;
-            o.cx = sp.center.x; o.cy = sp.center.y; o.cz = sp.center.z; o.radius = sp.radius;
-            o.id = (int)id; o.rank = (int)rank; o.mat = sp.material; o.inv_radius = sp.inv_radius;
+            o.cx = sp.center.x; o.cy = sp.center.y; o.cz = sp.center.z; o.radius_arg = sp.radius_arg;
+            o.id = (int)id; o.rank = (int)rank; o.mat = sp.material; o.inv_radius = sp.inv_radius; o.sure = sphere_sure_term(sp.center, sp.radius); o.pad0 = o.pad1 = o.pad2 = 0;
             flat.push_back(o);
         }
     }

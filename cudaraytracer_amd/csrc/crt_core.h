@@ -176,14 +176,94 @@ CRT_HD bool triangle_t(f3 a, f3 b, f3 c, f3 o, f3 d, float tmin, float &t_out)
 // triangle.h:75: the upper half of the interval test, against the running closest_so_far
 CRT_HD bool triangle_accepts(float t, float closest) { return !(t > closest + 1e-7f); }
 
+// aabb.h:72-92 fastAABBIntersect, literally (glm::min(a, b) = (b < a) ? b : a, glm::max(a, b) = (a < b) ? b : a, so a NaN
+// from 0 * inf travels the way it does there).  The walk's own box tests only prune and never use this; it is evaluated for
+// the one box whose verdict the sphere test does not imply (below).
+CRT_HD float glm_min(float a, float b) { return (b < a) ? b : a; }
+CRT_HD float glm_max(float a, float b) { return (a < b) ? b : a; }
+// (Not inlined on the device: it only runs on the rare careful path, and inlined there its temporaries raise the register
+// pressure of the whole kernel -- scratch spills on the common path, +5 % frame time.)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __attribute__((noinline)) bool reference_box_test(f3 bmin, f3 bmax, f3 o, f3 d)
+#else
+inline bool reference_box_test(f3 bmin, f3 bmax, f3 o, f3 d)
+#endif
+{
+    const float eps = 1e-7f;
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    const float t0x = (bmin.x - o.x) * ix, t0y = (bmin.y - o.y) * iy, t0z = (bmin.z - o.z) * iz;
+    const float t1x = (bmax.x - o.x) * ix, t1y = (bmax.y - o.y) * iy, t1z = (bmax.z - o.z) * iz;
+    const float nx = glm_min(t0x, t1x) - eps, ny = glm_min(t0y, t1y) - eps, nz = glm_min(t0z, t1z) - eps;
+    const float fx = glm_max(t0x, t1x) + eps, fy = glm_max(t0y, t1y) + eps, fz = glm_max(t0z, t1z) + eps;
+    const float t_near = glm_max(glm_max(nx, ny), nz);
+    const float t_far = glm_min(glm_min(fx, fy), fz);
+    return t_near <= t_far && t_far > 0.0f;
+}
+
 // sphere.h:22-41.  The reference tries the near root, then the far root, each against [tmin, closest]; since
 // far >= near, the root it can return is the first one >= tmin, accepted iff <= closest (sphere_accepts).
-CRT_HD bool sphere_t(f3 center, float radius, f3 o, f3 d, float tmin, float &t_out)
+// `radius_arg` is the constructor's argument: the sphere's radius is max(0, radius_arg) (sphere.h:11), its leaf box
+// center -+ radius_arg, ordered per axis (sphere.h:12-15, aabb.h:12-16) and NOT padded.
+// The reference only reaches Sphere::hit through the boxes of the sphere's leaf and of the leaf's ancestors (bvh.h), and for
+// a sphere its own test does not imply theirs: the discriminant b*b - a*c cancels (unnormalised directions, |d| ~ 14 for a
+// camera ray), so a ray that passes ~1e-4 OUTSIDE the silhouette can come out of it as a hit, and where the silhouette
+// touches the box -- the six axis-extreme points -- such a ray misses the box and the reference never tests the sphere.
+// (Found by the parity fuzz, tools/fuzz_parity.py: about one ray in 1e9 of a sphere scene.)  So a sphere hit also has to
+// pass the reference's test of the sphere's own box, in the reference's arithmetic.  The ancestors' boxes need no test:
+// they contain the leaf box, and every operation of the slab test is monotone in the box coordinates (subtract, multiply by
+// a fixed reciprocal, min / max, -+ eps), so -- NaN cases aside, DESIGN.md section 2 -- a ray that passes the test of the
+// leaf box passes theirs.  Triangles need none of this: their leaf boxes are padded by 1e-4 (triangle.h), two orders of
+// magnitude above the slack (1e-7 in u, v) and the rounding (~1e-6 at these scene sizes) of Triangle::hit.
+//
+// The literal test costs three IEEE divisions and ~60 further operations: +6.6 % of the headline frame when every sphere hit pays
+// it (the ground sphere is a candidate of nearly every ray), and still +5 % when it merely sits in a branch of the common path
+// (register pressure).  So the common path (STRICT = false) never evaluates it: sphere_hit_implies_box() decides nearly all hits
+// from what Sphere::hit has already computed, and a hit it cannot vouch for (1 in ~4000 on the cats frame) is taken PROVISIONALLY
+// and reported in `doubt`: the search then goes the careful way the ties go (crt_traverse.h: refold), which repeats the nearest-hit
+// walk with STRICT = true -- the literal test for every sphere hit.
+// The proof, with rounding bounds (u = 2^-24, q = |oc|^2, G = |c|inf + r): the EXACT ray passes through the ball of radius
+// r - u G (which lies inside the float-rounded box) ahead of the origin, over a parameter interval long enough for the float slab
+// test to see it, whenever  disc' >= u a W,  b' > 0  and  c' >= 0  (the primes: as computed), with W = 28 q + r (24 r + 8 |c|inf):
+//   * |disc' - disc| <= u a (19 q + 6 r^2) for the operations of Sphere::hit (oc, the three dots, fma(-r, r, q), a * c,
+//     fma(b, b, -ac));
+//   * shrinking the ball by u G costs at most 2 a r u G of discriminant;
+//   * every plane time of the slab test carries a relative error <= 3u (subtract, reciprocal, multiply), so near' <= far' is
+//     certain once the interval is >= 12u times its larger end, i.e. disc >= 37 u^2 b^2 -- far below the two terms above;
+//   * the interval ends at a positive time (the reference also asks t_far > 0) if the centre lies ahead, b > 0: with c' >= 0 the
+//     first condition gives b'^2 >= 27 u a q, i.e. |b'| >= 5e-4 sqrt(a q), against |b' - b| <= 4u sqrt(a q).
+// W covers all of these with room to spare (and for the rounding of the bound itself); its ray-independent part is evaluated at
+// commit (sphere_sure_term, kept in the sphere's record), which leaves one fma, one multiplication and three comparisons per hit.
+// A ray that starts INSIDE the sphere or leaves its surface (c' < 0 or b' <= 0: the far root, 0 +- noise for a leaving ray, can
+// exceed tmin) gets a second chance, as does everything else the first test cannot vouch for: if the origin lies strictly between
+// the planes as the reference rounds them, then in every axis the two plane distances have opposite signs, their products with
+// 1/d keep those signs exactly, and t_near' <= -eps < eps <= t_far' whatever the direction.  (It matters for the reference scene
+// itself: the ground sphere touches its box right under the models, where short rays leave the ground.)
+// What neither proves (a band ~ 1e-3 |oc|^2 / r wide along the silhouette -- on the cats frame the rays that graze the horizon,
+// ~2e-5 of all -- NaN, r = 0 seen from outside the box) is a doubt.  tools/sphere_box_audit.py: no hit the shortcut vouches for
+// fails the literal test in 1e8 rays made to be hard for it (and a bound 50x smaller fails thousands).
+CRT_HD float sphere_sure_term(f3 center, float radius)
 {
+    const float cmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(center.x), __builtin_fabsf(center.y)), __builtin_fabsf(center.z));
+    return radius * fma1(8.0f, cmax, 24.0f * radius) * 5.9604644775390625e-08f;
+}
+CRT_HD bool sphere_hit_implies_box(float sure, float a, float b, float q, float c, float discriminant)
+{
+    return discriminant >= a * fma1(28.0f * 5.9604644775390625e-08f, q, sure) && b > 0.0f && c >= 0.0f;
+}
+CRT_HD bool strictly_inside_box(f3 center, float h, f3 o)
+{
+    return center.x - h < o.x && o.x < center.x + h && center.y - h < o.y && o.y < center.y + h && center.z - h < o.z && o.z < center.z + h;
+}
+
+template <bool STRICT>
+CRT_HD bool sphere_t(f3 center, float radius_arg, float sure, f3 o, f3 d, float tmin, float &t_out, bool &doubt)
+{
+    const float radius = (0.0f < radius_arg) ? radius_arg : 0.0f; // std::max(0.0f, radius)
     const f3 oc = center - o;
     const float a = dot(d, d);
     const float b = dot(d, oc);
-    const float c = fma1(-radius, radius, dot(oc, oc));
+    const float q = dot(oc, oc);
+    const float c = fma1(-radius, radius, q);
     const float discriminant = fma1(b, b, -(a * c));
     if (discriminant < 0) return false;
     const float sd = __builtin_sqrtf(discriminant);
@@ -191,6 +271,13 @@ CRT_HD bool sphere_t(f3 center, float radius, f3 o, f3 d, float tmin, float &t_o
     if (!(root >= tmin)) {
         root = (b + sd) / a;
         if (!(root >= tmin)) return false;
+    }
+    const float h = __builtin_fabsf(radius_arg); // center - r < center + r for r > 0, the other way round for r < 0: the same box
+    if (STRICT) {
+        if (!reference_box_test(mk3(center.x - h, center.y - h, center.z - h), mk3(center.x + h, center.y + h, center.z + h), o, d)) return false;
+    } else {
+        doubt = !sphere_hit_implies_box(sure, a, b, q, c, discriminant);
+        if (doubt) doubt = !strictly_inside_box(center, h, o);
     }
     t_out = root;
     return true;
@@ -202,7 +289,8 @@ CRT_HD bool sphere_accepts(float t, float closest) { return t <= closest; }
 // ---------------------------------------------------------------------------------------------------------
 struct Material { int type; float r, g, b; float param; int tex; int pad0, pad1; };               // 32 B
 struct Texture { int type; float ar, ag, ab; float br, bg, bb; float inv_scale; };                // 32 B
-struct Sphere { float cx, cy, cz, radius; int id; int rank; int mat; float inv_radius; };         // 32 B; inv_radius: RN(1 / radius) if commit proved div3_exact with it, else 0
+struct Sphere { float cx, cy, cz, radius_arg; int id; int rank; int mat; float inv_radius; float sure; int pad0, pad1, pad2; }; // 48 B; radius_arg: the constructor's argument (radius = max(0, radius_arg), sphere.h:11); inv_radius: RN(1 / radius) if commit proved div3_exact with it, else 0; sure: sphere_sure_term()
+CRT_HD float sphere_radius(float radius_arg) { return (0.0f < radius_arg) ? radius_arg : 0.0f; }
 // Device record of a material joined with its texture (48 B, built at commit): one fetch per shaded hit instead
 // of material -> texture.  Colour a/b: the texture of a Lambertian / DiffuseLight (texture.h), the albedo of a Metal
 // (material.h:48) and (1,1,1) for a Dielectric (material.h:66), so that every material's colour is texture_value().

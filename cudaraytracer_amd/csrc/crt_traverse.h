@@ -77,7 +77,7 @@ struct SceneView {
 };
 
 #define CRT_BVH_NONE 0x7FFFFFFF
-// bit 30 of a slot's rank word: the slot holds a sphere ([centre, id][radius, -, -, rank][-, -, -, material]); the same
+// bit 30 of a slot's rank word: the slot holds a sphere ([centre, id][radius argument, 1 / radius or 0, sphere_sure_term, rank][-, -, -, material]); the same
 // bit in a hit code says "sphere slot" (codes: triangle slot < ntris <= flat sphere < 2^30 <= sphere slot)
 #define CRT_SPHERE_SLOT 0x40000000
 #define CRT_TIE_WINDOW 1e-6f
@@ -95,6 +95,9 @@ struct NoCounters {
     CRT_HD void shade() {}
 };
 
+// MODE_CLOSEST: the nearest-hit walk of the common path (sphere hits decided by sphere_hit_implies_box or taken provisionally, see
+// crt_core.h: sphere_t).  MODE_NEXT_RANK: the careful path's extraction walk, with the reference's literal box test for every
+// sphere hit.
 enum { MODE_CLOSEST = 0, MODE_NEXT_RANK = 1 };
 
 // State of one search.  code: triangle slot, or ntris + sphere index; -1 = nothing.
@@ -103,7 +106,7 @@ struct Search {
     int code;
     int mat;       // material id of `code` (carried so that the shading record is fetched without waiting for the primitive)
     int rank;      // MODE_NEXT_RANK: rank of the candidate found (smallest rank > after_rank)
-    int near_tie;  // MODE_CLOSEST: 1 when two candidates within CRT_TIE_WINDOW of each other were seen (an int: a lane
+    int near_tie;  // MODE_CLOSEST: 1 when two candidates within CRT_TIE_WINDOW of each other were seen, or a sphere hit was taken provisionally (an int: a lane
                    // mask would be merged with scalar instructions at every join of the walk loop).  MODE_NEXT_RANK: 0, or -1 to
                    // search for the largest rank instead (`rank` then holds ~rank, and after_rank must be INT_MIN)
 };
@@ -206,7 +209,11 @@ CRT_HD void trav_spheres(const SceneView &sc, f3 o, f3 d, float tmin, Search &s,
         const Sphere sp = load_uniform(sc.spheres, k);
         float t;
         cnt.sphere();
-        if (sphere_t(mk3(sp.cx, sp.cy, sp.cz), sp.radius, o, d, tmin, t)) offer<MODE>(s, t, (int)(sc.ntris + k), sp.mat, sp.rank, after_rank, t_hi);
+        bool doubt = false;
+        if (sphere_t<MODE != MODE_CLOSEST>(mk3(sp.cx, sp.cy, sp.cz), sp.radius_arg, sp.sure, o, d, tmin, t, doubt)) {
+            offer<MODE>(s, t, (int)(sc.ntris + k), sp.mat, sp.rank, after_rank, t_hi);
+            if (MODE == MODE_CLOSEST) s.near_tie = doubt ? 1 : s.near_tie;
+        }
     }
 }
 
@@ -391,8 +398,10 @@ CRT_HD void trav_leaf(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, in
         const int rank_word = f2i(tb.w);
         if (Counters::sphere_slots && (rank_word & CRT_SPHERE_SLOT)) { // only in scenes whose spheres went into the tree
             cnt.sphere();
-            if (sphere_t(mk3(ta.x, ta.y, ta.z), tb.x, o, d, tmin, t)) {
+            bool doubt = false;
+            if (sphere_t<MODE != MODE_CLOSEST>(mk3(ta.x, ta.y, ta.z), tb.x, tb.z, o, d, tmin, t, doubt)) {
                 offer<MODE>(s, t, (int)(first + k) | CRT_SPHERE_SLOT, f2i(tc.w), rank_word & ~CRT_SPHERE_SLOT, after_rank, t_hi);
+                if (MODE == MODE_CLOSEST) s.near_tie = doubt ? 1 : s.near_tie;
                 if (MODE == MODE_CLOSEST) tv.hi = s.t - tv.shift + CRT_TIE_WINDOW;
             }
             continue;
@@ -442,6 +451,12 @@ template <class Stack, class Counters, int WIDE = -1>
 CRT_HD int refold(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float t_min, float &t_hit, int &mat_hit, Stack &stack, Counters &cnt, Search &n,
                   Trav &tv)
 {
+    // Provisional sphere hits (crt_core.h: sphere_t) come here too, with or without a tie.  Every walk below applies the reference's
+    // literal box test to sphere hits, so a provisional hit that the test turns away is simply not among the candidates.  If it
+    // had supplied t_min itself (it also pruned the common path's walk then), the valid candidates lie anywhere above t_min: those
+    // inside the window are folded as usual -- t_min is only used as a lower bound of `closest` -- and if the window holds none the
+    // fold is repeated WITHOUT a window, which is the reference's own walk (every primitive whose test succeeds, in rank order,
+    // no distance culling).  That costs a walk per candidate along the whole ray and happens about once in 1e9 rays.
     float t_hi = t_min + CRT_TIE_WINDOW;
     float closest = tmax;
     int win = -1;
@@ -480,6 +495,7 @@ CRT_HD int refold(const SceneView &sc, f3 o, f3 d, float tmin, float tmax, float
             }
             after = n.rank;
         }
+        if (win < 0 && t_hi < FLT_MAX) { t_hi = FLT_MAX; continue; } // t_min was a provisional hit that the box test turned away
         if (!(reach > t_hi)) break;
         t_hi = reach + CRT_TIE_WINDOW;
     }
@@ -559,12 +575,12 @@ CRT_HD Surface surface_at(const SceneView &sc, int code, f3 o, f3 d, float t)
     } else if (SPHERE_SLOTS && (code & CRT_SPHERE_SLOT)) {
         const size_t k = 3 * (size_t)(code & ~CRT_SPHERE_SLOT);
         const q4 ta = load_global(sc.tris, k), tb = load_global(sc.tris, k + 1);
-        const f3 outward = div3_exact(r.point - mk3(ta.x, ta.y, ta.z), tb.x, tb.y); // sphere.h:45
+        const f3 outward = div3_exact(r.point - mk3(ta.x, ta.y, ta.z), sphere_radius(tb.x), tb.y); // sphere.h:45
         r.normal = face_normal(d, outward, r.front_face);
         r.prim = f2i(ta.w);
     } else {
         const Sphere sp = load_global(sc.spheres, (uint32_t)code - sc.ntris);
-        const f3 outward = div3_exact(r.point - mk3(sp.cx, sp.cy, sp.cz), sp.radius, sp.inv_radius);
+        const f3 outward = div3_exact(r.point - mk3(sp.cx, sp.cy, sp.cz), sphere_radius(sp.radius_arg), sp.inv_radius);
         r.normal = face_normal(d, outward, r.front_face);
         r.prim = sp.id;
     }

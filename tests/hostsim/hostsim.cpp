@@ -272,3 +272,27 @@ extern "C" void hostsim_div3_exact(float s, const float *a, uint32_t n, float *q
         q[3 * k] = r.x; q[3 * k + 1] = r.y; q[3 * k + 2] = r.z;
     }
 }
+
+// crt_core.h: sphere_t decides most sphere hits' box test from the sphere arithmetic (sphere_hit_implies_box) and evaluates the
+// reference's literal slab test (reference_box_test) for the rest.  Audit of that shortcut over n rays against one sphere:
+// out[0] = hits (root >= tmin), [1] = of them decided by the shortcut, [2] = of them passing the literal test, [3] = VIOLATIONS:
+// the shortcut said "implied" and the literal test fails (must be 0).
+extern "C" void hostsim_sphere_box_audit(const float center_[3], float radius_arg, const float *o_, const float *d_, uint64_t n, float tmin, uint64_t *out)
+{
+    using namespace crt;
+    const f3 center = mk3(center_[0], center_[1], center_[2]);
+    const float radius = sphere_radius(radius_arg), h = __builtin_fabsf(radius_arg);
+    const f3 lo = mk3(center.x - h, center.y - h, center.z - h), hi = mk3(center.x + h, center.y + h, center.z + h);
+    out[0] = out[1] = out[2] = out[3] = 0;
+    for (uint64_t k = 0; k < n; k++) {
+        const f3 o = mk3(o_[3 * k], o_[3 * k + 1], o_[3 * k + 2]), d = mk3(d_[3 * k], d_[3 * k + 1], d_[3 * k + 2]);
+        const f3 oc = center - o;
+        const float a = dot(d, d), b = dot(d, oc), q = dot(oc, oc), c = fma1(-radius, radius, q), disc = fma1(b, b, -(a * c));
+        if (disc < 0) continue;
+        const float sd = __builtin_sqrtf(disc);
+        float root = (b - sd) / a;
+        if (!(root >= tmin)) { root = (b + sd) / a; if (!(root >= tmin)) continue; }
+        const bool implied = sphere_hit_implies_box(sphere_sure_term(center, radius), a, b, q, c, disc) || strictly_inside_box(center, h, o), literal = reference_box_test(lo, hi, o, d);
+        out[0]++; out[1] += implied; out[2] += literal; out[3] += implied && !literal;
+    }
+}
