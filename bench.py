@@ -56,7 +56,7 @@ def lane_ops(st, node_width=2):
 
 
 def algorithmic_bytes(st, width, height, node_width=2):
-    return 32.0 * node_width * st.nodes + 48.0 * st.tri_tests + 32.0 * st.sphere_tests + 12.0 * width * height
+    return 32.0 * node_width * st.nodes + 48.0 * st.tri_tests + 48.0 * st.sphere_tests + 12.0 * width * height
 
 
 def pmc_traffic(workload, world):
@@ -291,7 +291,7 @@ def main():
                                  "note": "achieved = PMC HBM bytes per launch (traffic) / kernel time; the algorithmic bytes are priced in l2_lds"},
                          "l2_lds": {"bound": "l2", "achieved": abytes / ksec / 1e9, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": abytes / ksec / 1e9 / L2_PEAK_GBS,
                                     "infinity_cache_gather_peak": INFINITY_CACHE_GATHER_GBS, "frac_of_infinity_cache_gather": abytes / ksec / 1e9 / INFINITY_CACHE_GATHER_GBS,
-                                    "note": "algorithmic node (64 B; 128 B with four children) + triangle (48 B) + sphere (32 B) + framebuffer bytes / kernel time: a request rate served by the "
+                                    "note": "algorithmic node (64 B; 128 B with four children) + triangle (48 B) + sphere (48 B) + framebuffer bytes / kernel time: a request rate served by the "
                                             "LDS node copy, L1 and L2 when the scene (%d KiB) is cache resident; for scenes beyond L2 (the 1 M-triangle grid) the "
                                             "Infinity-Cache gather rate is the memory-side bound"
                                             % ((info.node_bytes + info.triangle_bytes + info.sphere_bytes) // 1024)}},
