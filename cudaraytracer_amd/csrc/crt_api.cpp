@@ -679,7 +679,7 @@ static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
         } else {
             Sphere o;
             o.cx = sp.center.x; o.cy = sp.center.y; o.cz = sp.center.z; o.radius_arg = sp.radius_arg;
-            o.id = (int)id; o.rank = (int)rank; o.mat = sp.material; o.inv_radius = sp.inv_radius; o.sure = sphere_sure_term(sp.center, sp.radius); o.pad0 = o.pad1 = o.pad2 = 0;
+            o.id = (int)id; o.rank = (int)rank; o.mat = sp.material; o.inv_radius = sp.inv_radius; o.sure = sphere_sure_term(sp.center, sp.radius); o.radius = sp.radius; o.pad1 = o.pad2 = 0;
             flat.push_back(o);
         }
     }

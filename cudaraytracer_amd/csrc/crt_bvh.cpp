@@ -155,7 +155,7 @@ struct Builder {
             if (refs[i].tri >= tris.size()) { // sphere slot
                 const BvhSphere &sp = spheres[refs[i].tri - tris.size()];
                 q4 a, b, c;
-                a.x = sp.s.center.x; a.y = sp.s.center.y; a.z = sp.s.center.z; b.x = sp.s.radius_arg; b.y = sp.s.inv_radius; b.z = sphere_sure_term(sp.s.center, sp.s.radius); c.x = c.y = c.z = 0.0f;
+                a.x = sp.s.center.x; a.y = sp.s.center.y; a.z = sp.s.center.z; b.x = sp.s.radius_arg; b.y = sp.s.inv_radius; b.z = sphere_sure_term(sp.s.center, sp.s.radius); c.x = sp.s.radius; c.y = c.z = 0.0f;
                 const int id = (int)sp.id, rk = (int)(sp.rank | CRT_SPHERE_SLOT), mat = sp.s.material;
                 std::memcpy(&a.w, &id, 4); std::memcpy(&b.w, &rk, 4); std::memcpy(&c.w, &mat, 4);
                 out.tris.push_back(a); out.tris.push_back(b); out.tris.push_back(c);

@@ -43,7 +43,7 @@ struct FlatBvh {
 struct BvhSphere { HostSphere s; uint32_t id; uint32_t rank; };
 
 // SAH (binned) BVH over the primitives' reference boxes, inflated by a rounding margin.  rank/ids are carried
-// into the 48-byte slots; a sphere slot is [centre, id][radius argument, inv_radius, sphere_sure_term, rank | CRT_SPHERE_SLOT][0, 0, 0, material].
+// into the 48-byte slots; a sphere slot is [centre, id][radius argument, inv_radius, sphere_sure_term, rank | CRT_SPHERE_SLOT][radius, 0, 0, material].
 // rank[i] is the rank of triangle i.  max_leaf in 1..8.
 void build_bvh(const std::vector<HostTriangle> &tris, const std::vector<uint32_t> &rank, const std::vector<BvhSphere> &spheres, uint32_t max_leaf,
                FlatBvh &out);

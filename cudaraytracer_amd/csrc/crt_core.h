@@ -256,9 +256,9 @@ CRT_HD bool strictly_inside_box(f3 center, float h, f3 o)
 }
 
 template <bool STRICT>
-CRT_HD bool sphere_t(f3 center, float radius_arg, float sure, f3 o, f3 d, float tmin, float &t_out, bool &doubt)
+CRT_HD bool sphere_t(f3 center, float radius, float radius_arg, float sure, f3 o, f3 d, float tmin, float &t_out, bool &doubt)
 {
-    const float radius = (0.0f < radius_arg) ? radius_arg : 0.0f; // std::max(0.0f, radius)
+    // radius = sphere_radius(radius_arg) = std::max(0.0f, radius_arg) (sphere.h:11), evaluated at commit and kept in the record
     const f3 oc = center - o;
     const float a = dot(d, d);
     const float b = dot(d, oc);
@@ -289,7 +289,7 @@ CRT_HD bool sphere_accepts(float t, float closest) { return t <= closest; }
 // ---------------------------------------------------------------------------------------------------------
 struct Material { int type; float r, g, b; float param; int tex; int pad0, pad1; };               // 32 B
 struct Texture { int type; float ar, ag, ab; float br, bg, bb; float inv_scale; };                // 32 B
-struct Sphere { float cx, cy, cz, radius_arg; int id; int rank; int mat; float inv_radius; float sure; int pad0, pad1, pad2; }; // 48 B; radius_arg: the constructor's argument (radius = max(0, radius_arg), sphere.h:11); inv_radius: RN(1 / radius) if commit proved div3_exact with it, else 0; sure: sphere_sure_term()
+struct Sphere { float cx, cy, cz, radius_arg; int id; int rank; int mat; float inv_radius; float sure; float radius; int pad1, pad2; }; // 48 B; radius_arg: the constructor's argument, radius = max(0, radius_arg) (sphere.h:11); inv_radius: RN(1 / radius) if commit proved div3_exact with it, else 0; sure: sphere_sure_term()
 CRT_HD float sphere_radius(float radius_arg) { return (0.0f < radius_arg) ? radius_arg : 0.0f; }
 // Device record of a material joined with its texture (48 B, built at commit): one fetch per shaded hit instead
 // of material -> texture.  Colour a/b: the texture of a Lambertian / DiffuseLight (texture.h), the albedo of a Metal

@@ -77,7 +77,7 @@ struct SceneView {
 };
 
 #define CRT_BVH_NONE 0x7FFFFFFF
-// bit 30 of a slot's rank word: the slot holds a sphere ([centre, id][radius argument, 1 / radius or 0, sphere_sure_term, rank][-, -, -, material]); the same
+// bit 30 of a slot's rank word: the slot holds a sphere ([centre, id][radius argument, 1 / radius or 0, sphere_sure_term, rank][radius, -, -, material]); the same
 // bit in a hit code says "sphere slot" (codes: triangle slot < ntris <= flat sphere < 2^30 <= sphere slot)
 #define CRT_SPHERE_SLOT 0x40000000
 #define CRT_TIE_WINDOW 1e-6f
@@ -210,7 +210,7 @@ CRT_HD void trav_spheres(const SceneView &sc, f3 o, f3 d, float tmin, Search &s,
         float t;
         cnt.sphere();
         bool doubt = false;
-        if (sphere_t<MODE != MODE_CLOSEST>(mk3(sp.cx, sp.cy, sp.cz), sp.radius_arg, sp.sure, o, d, tmin, t, doubt)) {
+        if (sphere_t<MODE != MODE_CLOSEST>(mk3(sp.cx, sp.cy, sp.cz), sp.radius, sp.radius_arg, sp.sure, o, d, tmin, t, doubt)) {
             offer<MODE>(s, t, (int)(sc.ntris + k), sp.mat, sp.rank, after_rank, t_hi);
             if (MODE == MODE_CLOSEST) s.near_tie = doubt ? 1 : s.near_tie;
         }
@@ -399,7 +399,7 @@ CRT_HD void trav_leaf(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, in
         if (Counters::sphere_slots && (rank_word & CRT_SPHERE_SLOT)) { // only in scenes whose spheres went into the tree
             cnt.sphere();
             bool doubt = false;
-            if (sphere_t<MODE != MODE_CLOSEST>(mk3(ta.x, ta.y, ta.z), tb.x, tb.z, o, d, tmin, t, doubt)) {
+            if (sphere_t<MODE != MODE_CLOSEST>(mk3(ta.x, ta.y, ta.z), tc.x, tb.x, tb.z, o, d, tmin, t, doubt)) {
                 offer<MODE>(s, t, (int)(first + k) | CRT_SPHERE_SLOT, f2i(tc.w), rank_word & ~CRT_SPHERE_SLOT, after_rank, t_hi);
                 if (MODE == MODE_CLOSEST) s.near_tie = doubt ? 1 : s.near_tie;
                 if (MODE == MODE_CLOSEST) tv.hi = s.t - tv.shift + CRT_TIE_WINDOW;
@@ -575,12 +575,12 @@ CRT_HD Surface surface_at(const SceneView &sc, int code, f3 o, f3 d, float t)
     } else if (SPHERE_SLOTS && (code & CRT_SPHERE_SLOT)) {
         const size_t k = 3 * (size_t)(code & ~CRT_SPHERE_SLOT);
         const q4 ta = load_global(sc.tris, k), tb = load_global(sc.tris, k + 1);
-        const f3 outward = div3_exact(r.point - mk3(ta.x, ta.y, ta.z), sphere_radius(tb.x), tb.y); // sphere.h:45
+        const f3 outward = div3_exact(r.point - mk3(ta.x, ta.y, ta.z), sphere_radius(tb.x), tb.y); // sphere.h:45 (the clamped radius is in the third quad; one comparison here is cheaper than its fetch)
         r.normal = face_normal(d, outward, r.front_face);
         r.prim = f2i(ta.w);
     } else {
         const Sphere sp = load_global(sc.spheres, (uint32_t)code - sc.ntris);
-        const f3 outward = div3_exact(r.point - mk3(sp.cx, sp.cy, sp.cz), sphere_radius(sp.radius_arg), sp.inv_radius);
+        const f3 outward = div3_exact(r.point - mk3(sp.cx, sp.cy, sp.cz), sp.radius, sp.inv_radius);
         r.normal = face_normal(d, outward, r.front_face);
         r.prim = sp.id;
     }
