@@ -1,3 +1,6 @@
+# Round-end evidence on the GPU box, one call: the rocprofv3 passes of the default workload (profiles/run_rocprof.sh), the default bench line
+# with its CPU baseline, the other four workloads, and a 300 s parity campaign -> gpurun_out/final_r3_v3/ and gpurun_out/prof_r3_v3/
+# (summarised into profiles/ by tools/summarize_prof.py).  usage: gpurun --timeout 1200 -- bash tools/collect_round_evidence.sh
 set -u
 O=gpurun_out/final_r3_v3; mkdir -p $O
 bash profiles/run_rocprof.sh r3_v3 > $O/rocprof.log 2>&1 || { tail -5 $O/rocprof.log; exit 1; }

@@ -1,3 +1,6 @@
+"""The two frames of the round-3 parity campaign (tools/fuzz_parity.py, seed 2) that differed from the oracle, rendered on the GPU at their
+own parameters and with three node-cache settings: prints ray counts, differing ids and differing image values (all 0 since the
+sphere box test).  usage (GPU box): python tools/fuzz_repro.py"""
 import os, sys
 sys.path.insert(0, '.')
 import numpy as np
