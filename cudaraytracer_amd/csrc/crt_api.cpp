@@ -418,6 +418,7 @@ struct crt_scene {
     size_t nslots = 0;
     std::vector<Sphere> flat_spheres; // the spheres that are tested before the walk (the others are slots of the tree)
     bool sphere_slots = false;        // some spheres went into the tree
+    float sphere_slot_rmax = 0.0f;    // the largest radius among them (SceneView::sphere_slots carries it)
     Tuning tuning;
     std::vector<DeviceScene> dev;     // dev[0]: the copy crt_render uses; one per logical rank after crt_scene_commit_devices
     MultiState multi;
@@ -685,6 +686,8 @@ static int prepare_host(crt_scene *s, int build_device, uint32_t flags)
     }
     if (flat.size() > 4096) return fail(CRT_ERR_LIMIT, "crt_scene_commit: more than 4096 spheres outside the tree");
     s->sphere_slots = !tree_spheres.empty();
+    s->sphere_slot_rmax = FLT_MIN;
+    for (const BvhSphere &sp : tree_spheres) s->sphere_slot_rmax = std::max(s->sphere_slot_rmax, sp.s.radius);
 
     if (!gpu_built) {
         build_bvh(s->tris, s->rank, tree_spheres, max_leaf, s->bvh);
@@ -791,7 +794,8 @@ static int upload_replica(crt_scene *s, DeviceScene &d, int device)
     v.nodes = (const q4 *)d.d_nodes; v.tris = (const q4 *)d.d_tris; v.spheres = (const Sphere *)d.d_spheres;
     v.shades = (const Shade *)d.d_shades; v.normals = (const q4 *)d.d_normals;
     v.root_ref = s->bvh.root_ref; v.wide = s->bvh.wide ? 1u : 0u; v.nnodes = (uint32_t)(s->bvh.nodes.size() / (s->bvh.wide ? 8 : 4)); v.ntris = (uint32_t)s->nslots;
-    v.nspheres = (uint32_t)s->flat_spheres.size(); v.sphere_slots = s->sphere_slots ? 1u : 0u;
+    v.nspheres = (uint32_t)s->flat_spheres.size(); v.sphere_slots = 0u;
+    if (s->sphere_slots) std::memcpy(&v.sphere_slots, &s->sphere_slot_rmax, 4);
     v.root_min = s->bvh.root_box.mn; v.root_max = s->bvh.root_box.mx;
     return CRT_OK;
 }

@@ -47,6 +47,14 @@ CRT_HD int f2i(float f)
     union { float f; int i; } u; u.f = f; return u.i;
 #endif
 }
+CRT_HD float i2f(int i)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __int_as_float(i);
+#else
+    union { float f; int i; } u; u.i = i; return u.f;
+#endif
+}
 
 // Node (4 x q4 = 64 B): [c0min.xyz, ref0] [c0max.xyz, ref1] [c1min.xyz, -] [c1max.xyz, -]
 // ref >= 0: index of a node; ref < 0: leaf, ~ref = (first_slot << 3) | (count - 1), count in 1..8.
@@ -71,7 +79,7 @@ struct SceneView {
     uint32_t nnodes;     // 64-byte nodes (breadth-first order: crt_bvh.cpp)
     uint32_t ntris;      // triangle slots
     uint32_t nspheres;   // flat list
-    uint32_t sphere_slots; // != 0: some slots of `tris` hold spheres (picks the kernel variant that tests for them)
+    uint32_t sphere_slots; // != 0: some slots of `tris` hold spheres (picks the kernel variant that tests for them); the bits of a float: the largest radius among them (at least FLT_MIN)
     uint32_t wide;         // != 0: `nodes` holds four-child nodes of 128 bytes (trav_inner4_from) instead of two-child nodes of 64
     f3 root_min, root_max;
 };
@@ -130,6 +138,7 @@ struct Trav {
     f3 idir, ood; // slab arithmetic: t' = b * idir - ood, origin re-based to the root-box entry
     float shift;  // t = t' + shift
     float hi;     // upper pruning bound in re-based time
+    float slack;  // sphere-slot scenes only (prune_limit): what a sphere's computed root may precede its box by, beyond the relative part
     int cur;      // current ref (node >= 0, leaf < 0) or CRT_BVH_NONE when the walk is over
 };
 
@@ -199,6 +208,22 @@ template <class Stack> struct stack_none { static constexpr int value = CRT_BVH_
 template <int NONE = CRT_BVH_NONE>
 CRT_HD bool is_inner(int ref) { return (unsigned)ref < (unsigned)NONE; }
 
+// How far the walk may prune.  A triangle's t lies inside the time interval of its boxes (padded by 1e-4), so
+// `best` + the tie window is the limit.  A sphere's computed root carries the cancellation of its discriminant and can lie BEFORE
+// the entry time of the sphere's own box: (4u |oc| + sqrt(u (19 |oc|^2 + 6 r^2))) / |d| <= 1.1e-3 (t_c + r / |d|) with t_c the time
+// of the closest approach to the centre (crt_core.h: the bounds of sphere_hit_implies_box).  Kernels for scenes with spheres in the
+// tree therefore prune at best * (1 + CRT_SPHERE_ROOT_REL) + slack, slack = CRT_SPHERE_ROOT_ABS * r_max / |d| per ray.  (That covers
+// roots of rays that do intersect the sphere; for a hit the arithmetic invents just outside the silhouette it is a mitigation, see
+// DESIGN.md section 2 "What remains unmatched".)
+#define CRT_SPHERE_ROOT_REL 2.5e-3f
+#define CRT_SPHERE_ROOT_ABS 1.0e-2f
+template <bool SS>
+CRT_HD float prune_limit(const SceneView &sc, const Trav &tv, float best)
+{
+    if (SS && sc.sphere_slots) return fma1(best, 1.0f + CRT_SPHERE_ROOT_REL, tv.slack);
+    return best;
+}
+
 // Spheres: a short flat list (ground + light in the reference scenes, scene.h:164-165), tested before the BVH.
 // MODE_CLOSEST: s.t must start at tmax (FLT_MAX).  MODE_NEXT_RANK: only candidates with t <= t_hi and
 // rank > after_rank are considered, s.rank must start at INT_MAX.
@@ -219,11 +244,12 @@ CRT_HD void trav_spheres(const SceneView &sc, f3 o, f3 d, float tmin, Search &s,
 
 // Root box of the triangle BVH against the current best t: sets up the slab registers.  Leaves
 // tv.cur = CRT_BVH_NONE if no node needs visiting.
-template <int MODE, int NONE = CRT_BVH_NONE>
+template <int MODE, int NONE = CRT_BVH_NONE, bool SS = true>
 CRT_HD void trav_root(const SceneView &sc, f3 o, f3 d, const Search &s, float t_hi, Trav &tv)
 {
     tv.cur = NONE;
     if (sc.root_ref == CRT_BVH_NONE) return;
+    if (SS && sc.sphere_slots) tv.slack = CRT_SPHERE_ROOT_ABS * i2f((int)sc.sphere_slots) / __builtin_sqrtf(dot(d, d));
     // slab arithmetic for pruning: idir finite, origin re-based to the root box entry so that rounding stays
     // small against the box margin wherever the ray starts.
     // (pruning only, so the 1-ulp hardware reciprocal is enough; it never touches a result)
@@ -233,13 +259,14 @@ CRT_HD void trav_root(const SceneView &sc, f3 o, f3 d, const Search &s, float t_
     const float az = (sc.root_min.z - o.z) * idir.z, bz = (sc.root_max.z - o.z) * idir.z;
     const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fminf(az, bz));
     const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
-    const float bound = ((MODE == MODE_CLOSEST) ? s.t : t_hi) + CRT_TIE_WINDOW;
+    const float limit = prune_limit<SS>(sc, tv, (MODE == MODE_CLOSEST) ? s.t : t_hi);
+    const float bound = limit + CRT_TIE_WINDOW;
     if (!(tn <= tf && tf >= 0.0f && tn <= bound)) return;
     tv.shift = __builtin_fmaxf(tn, 0.0f); // (the same trick here, min_no_nan's counterpart, measured 2.8 % SLOWER: the asm pins the schedule of the shade phase)
     const f3 ob = axpy(tv.shift, d, o);
     tv.idir = idir;
     tv.ood = mk3(ob.x * idir.x, ob.y * idir.y, ob.z * idir.z);
-    tv.hi = ((MODE == MODE_CLOSEST) ? s.t : t_hi) - tv.shift + CRT_TIE_WINDOW;
+    tv.hi = limit - tv.shift + CRT_TIE_WINDOW;
     tv.cur = sc.root_ref;
 }
 
@@ -247,7 +274,7 @@ template <int MODE, class Stack, class Counters>
 CRT_HD void trav_begin(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, int after_rank, float t_hi, Trav &tv, Stack &stack, Counters &cnt)
 {
     trav_spheres<MODE>(sc, o, d, tmin, s, after_rank, t_hi, cnt);
-    trav_root<MODE, stack_none<Stack>::value>(sc, o, d, s, t_hi, tv);
+    trav_root<MODE, stack_none<Stack>::value, Counters::sphere_slots>(sc, o, d, s, t_hi, tv);
     stack.reset();
 }
 
@@ -402,14 +429,14 @@ CRT_HD void trav_leaf(const SceneView &sc, f3 o, f3 d, float tmin, Search &s, in
             if (sphere_t<MODE != MODE_CLOSEST>(mk3(ta.x, ta.y, ta.z), tc.x, tb.x, tb.z, o, d, tmin, t, doubt)) {
                 offer<MODE>(s, t, (int)(first + k) | CRT_SPHERE_SLOT, f2i(tc.w), rank_word & ~CRT_SPHERE_SLOT, after_rank, t_hi);
                 if (MODE == MODE_CLOSEST) s.near_tie = doubt ? 1 : s.near_tie;
-                if (MODE == MODE_CLOSEST) tv.hi = s.t - tv.shift + CRT_TIE_WINDOW;
+                if (MODE == MODE_CLOSEST) tv.hi = prune_limit<Counters::sphere_slots>(sc, tv, s.t) - tv.shift + CRT_TIE_WINDOW;
             }
             continue;
         }
         cnt.tri();
         if (triangle_t(mk3(ta.x, ta.y, ta.z), mk3(tb.x, tb.y, tb.z), mk3(tc.x, tc.y, tc.z), o, d, tmin, t)) {
             offer<MODE>(s, t, (int)(first + k), f2i(tc.w), rank_word, after_rank, t_hi);
-            if (MODE == MODE_CLOSEST) tv.hi = s.t - tv.shift + CRT_TIE_WINDOW;
+            if (MODE == MODE_CLOSEST) tv.hi = prune_limit<Counters::sphere_slots>(sc, tv, s.t) - tv.shift + CRT_TIE_WINDOW;
         }
     }
     tv.cur = stack.pop();

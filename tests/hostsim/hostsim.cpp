@@ -52,7 +52,8 @@ SceneView host_view(const crt_scene *s, std::vector<Sphere> &spheres)
     spheres = s->flat_spheres;
     SceneView v{};
     v.nodes = s->bvh.nodes.data(); v.tris = s->bvh.tris.data(); v.spheres = spheres.data(); v.shades = s->shades.data(); v.normals = s->normals.data();
-    v.root_ref = s->bvh.root_ref; v.wide = s->bvh.wide ? 1u : 0u; v.nnodes = (uint32_t)(s->bvh.nodes.size() / (s->bvh.wide ? 8 : 4)); v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size(); v.sphere_slots = 1;
+    v.root_ref = s->bvh.root_ref; v.wide = s->bvh.wide ? 1u : 0u; v.nnodes = (uint32_t)(s->bvh.nodes.size() / (s->bvh.wide ? 8 : 4)); v.ntris = (uint32_t)(s->bvh.tris.size() / 3); v.nspheres = (uint32_t)spheres.size(); v.sphere_slots = 0;
+    if (s->sphere_slots) std::memcpy(&v.sphere_slots, &s->sphere_slot_rmax, 4); // (the host counters compile the sphere-slot code in; this switches its pruning slack as on the device)
     v.root_min = s->bvh.root_box.mn; v.root_max = s->bvh.root_box.mx;
     return v;
 }

@@ -997,3 +997,21 @@ def test_fuzz_findings_round_3_sphere_hits_outside_the_spheres_box(oracle, scene
             rgb, ids, st = s.render(cam, w, h, spp, want_ids=True, **kw)
             monkeypatch.delenv("CRT_KERNEL", raising=False)
             assert st.rays == rst.rays and np.array_equal(ids, rids) and np.array_equal(rgb.reshape(fb.shape), fb), (w, kernel)
+
+
+def test_spheres_hovering_above_a_floor_seen_from_below(oracle, scenes, capi):
+    """tests/test_host.py::test_a_sphere_root_before_its_own_box_is_not_pruned as frames on the GPU: 15 spheres 2e-4 above a floor,
+    cameras below the floor looking up (far away: the spheres' computed roots are noisy enough to come out in front of the floor)."""
+    from tests.test_host import _hovering_spheres
+    desc, _ = _hovering_spheres(scenes, capi, 2e-4)
+    s = scenes.build(desc, 0)
+    assert s.info().num_spheres == 15 and s.info().sphere_bytes == 0       # all of them in the tree
+    rs = oracle.RefScene(desc)
+    differs_from_the_floor = 0
+    for lookfrom, vfov in (((3.0, -40.0, 9.0), 8.0), ((-25.0, -30.0, 4.0), 9.0), ((0.5, -80.0, 0.3), 4.0)):
+        params, cam = scenes.make_camera(320, lookfrom=lookfrom, lookat=(0.0, 0.0, 0.0), vfov=vfov, defocus_angle=0.0, background=(0.6, 0.7, 0.9))
+        fb, rids, _, rst = rs.render(oracle.make_camera(params, 320), 320, 180, 2, max_depth=3)
+        rgb, ids, st = s.render(cam, 320, 180, 2, want_ids=True, max_depth=3)
+        assert st.rays == rst.rays and np.array_equal(ids, rids) and np.array_equal(rgb.reshape(fb.shape), fb), lookfrom
+        differs_from_the_floor += int((rids >= 2).sum())
+    assert differs_from_the_floor > 0                                       # spheres show through the floor, as in the reference

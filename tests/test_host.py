@@ -287,6 +287,42 @@ def test_negative_radius_argument(hostsim, oracle, scenes, capi):
     assert point_hits > 50
 
 
+def _hovering_spheres(scenes, capi, hover):
+    """15 spheres of radius 0.2 (more than 8: they go into the tree) `hover` above a two-triangle floor."""
+    desc = scenes._base()
+    desc["materials"].append(dict(type=capi.MAT_LAMBERTIAN, rgb=(0.5, 0.5, 0.5), param=0.0, texture=None))
+    centres = [(float(x), 0.2 + hover, float(z)) for x in range(-2, 3) for z in range(-1, 2)]
+    desc["spheres"] = [dict(center=c, radius=0.2, material=0) for c in centres]
+    v = np.array([[-50, 0, -50], [50, 0, -50], [50, 0, 50], [-50, 0, 50]], np.float32)
+    desc["meshes"].append(dict(vertices=v, indices=np.array([[0, 1, 2], [0, 2, 3]], np.uint32), material=0))
+    return desc, centres
+
+
+def test_a_sphere_root_before_its_own_box_is_not_pruned(hostsim, oracle, scenes, capi):
+    """A sphere's computed root carries its discriminant's cancellation and can lie before the entry time of the sphere's box.  Rays
+    from BELOW a floor, aimed under spheres that hover 2e-4 above it: the reference (no distance culling) takes the sphere whenever
+    its noisy root comes out smaller than the floor's t.  With the triangle walk's pruning limit (best + 1e-6) the product answered
+    the floor for ~10 % of these rays; kernels for scenes with spheres in the tree prune at the root's error bound (crt_traverse.h:
+    prune_limit; tools/sphere_prune_probe.py is the longer version of this test)."""
+    desc, centres = _hovering_spheres(scenes, capi, 2e-4)
+    s = hostsim.build(desc)
+    rs = oracle.RefScene(desc)
+    rng = np.random.default_rng(1)
+    sphere_in_front_of_its_box = 0
+    for _ in range(6000):
+        c = np.array(centres[rng.integers(len(centres))])
+        target = np.array([c[0], 0.0, c[2]]) + np.array([rng.normal(), 0, rng.normal()]) * 0.2 * 10.0 ** rng.uniform(-4, -1)
+        az, el = rng.uniform(0, 2 * np.pi), 10.0 ** rng.uniform(-2, 0.19)
+        u = np.array([np.cos(az) * np.cos(el), -np.sin(el), np.sin(az) * np.cos(el)])
+        o = (target + 10.0 ** rng.uniform(0, 2) * u).astype(np.float32)
+        d = (-u * 10.0 ** rng.uniform(-1, 1.3)).astype(np.float32)
+        ref = rs.trace(o, d)
+        prim, t, _ = hostsim.trace(s, o, d)
+        assert prim == ref[0] and (prim < 0 or t == ref[1]), (o, d, prim, t, ref)
+        sphere_in_front_of_its_box += 2 <= ref[0]            # prims 0, 1: the floor's triangles
+    assert sphere_in_front_of_its_box > 200                   # (measured ~600: the reference answers a sphere that lies BEHIND the floor)
+
+
 def test_fuzz_findings_round_3(hostsim, oracle, scenes):
     """The two frames tools/fuzz_parity.py found (one ray each whose sphere 'hit' lies outside the sphere's box), at their own parameters."""
     desc = scenes.random_spheres()
