@@ -1,9 +1,9 @@
-"""Probe of the one parity limit DESIGN.md section 2 states for spheres IN THE TREE (scenes with more than 8 spheres): 15 spheres of
+"""Probe of a parity case DESIGN.md section 2 describes for spheres IN THE TREE (scenes with more than 8 spheres): 15 spheres of
 radius 0.2 hovering HOVER (default 2e-4) above a two-triangle floor, rays from BELOW the floor aimed at the points under the
 spheres.  The reference does not cull by distance, so it takes the sphere whenever the sphere's computed root -- which carries the
-discriminant's cancellation, ~1e-4..1e-3 of t from 30 units away -- comes out smaller than the floor's t; the product has the floor first, prunes the
-sphere's node (its box is entered after the floor's t + 1e-6) and answers the floor.  Host stepper against the oracle; prints the
-number of rays that differ (HOVER=0, spheres resting on the floor: none; HOVER=2e-4: ~10 %).
+discriminant's cancellation, ~1e-4..1e-3 of t from 30 units away -- comes out smaller than the floor's t.  With the triangle walk's
+pruning limit (best + 1e-6) the product had the floor first, pruned the sphere's node and answered the floor for ~10 % of these rays;
+with crt_traverse.h's prune_limit for sphere-slot scenes: none.  Host stepper against the oracle; prints the number of rays that differ.
 usage: [HOVER=2e-4] python tools/sphere_prune_probe.py [rays]"""
 import os, sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
