@@ -11,15 +11,34 @@ from oracle import binding as oracle
 capi.RELOAD_TUNING_EACH_RENDER = True
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-NAMES = ["cat", "cats", "cat_checker", "random_spheres", "terrain"]
+NAMES = ["cat", "cats", "cat_checker", "random_spheres", "terrain", "spheres_on_a_floor"]
 BUILDERS = [0, capi.BUILD_GPU_SAH, capi.BUILD_GPU_LBVH]
 built, refs = {}, {}
 
 
+def spheres_on_a_floor():
+    """Spheres in the tree among triangles: 40 spheres hovering over, resting on, or sunk into a two-triangle floor (heights from -r
+    to a few 1e-4 above it), some touching each other, a glass one and a metal one among them, a light above; seen from above and
+    from BELOW the floor (a sphere's computed root can lie before its own box)."""
+    r = np.random.default_rng(99)
+    d = scenes._base()
+    d["materials"] += [dict(type=capi.MAT_LAMBERTIAN, rgb=(0.6, 0.5, 0.4), param=0.0, texture=None), dict(type=capi.MAT_DIELECTRIC, rgb=(1, 1, 1), param=1.5, texture=None),
+                       dict(type=capi.MAT_METAL, rgb=(0.8, 0.8, 0.7), param=0.1, texture=None), dict(type=capi.MAT_DIFFUSE_LIGHT, rgb=(4, 4, 4), param=0.0, texture=None)]
+    d["spheres"] = []
+    for k in range(40):
+        rad = float(r.choice([0.2, 0.2, 0.35, 0.05]))
+        lift = float(r.choice([0.0, 2e-5, 2e-4, 1e-3, -0.5 * rad, -rad]))
+        d["spheres"].append(dict(center=(float(r.uniform(-3, 3)), rad + lift, float(r.uniform(-2, 2))), radius=rad, material=int(r.choice([0, 0, 1, 2]))))
+    d["spheres"].append(dict(center=(0.0, 6.0, 0.0), radius=1.5, material=3))
+    v = np.array([[-30, 0, -30], [30, 0, -30], [30, 0, 30], [-30, 0, 30]], np.float32)
+    d["meshes"].append(dict(vertices=v, indices=np.array([[0, 1, 2], [0, 2, 3]], np.uint32), material=0))
+    return d
+
+
 def scene_for(name, flags):
     if (name, flags) not in built:
-        desc = getattr(scenes, name)() if name != "terrain" else scenes.terrain(24)
-        built[(name, flags)] = (desc, scenes.build(desc, 0, flags if name != "random_spheres" else 0))
+        desc = spheres_on_a_floor() if name == "spheres_on_a_floor" else getattr(scenes, name)() if name != "terrain" else scenes.terrain(24)
+        built[(name, flags)] = (desc, scenes.build(desc, 0, flags if name not in ("random_spheres", "spheres_on_a_floor") else 0))
     return built[(name, flags)]
 
 
@@ -43,6 +62,11 @@ while time.time() - t0 < budget:
     kw = dict(max_depth=int(rng.integers(1, 12)), seed=int(rng.integers(0, 2 ** 40)), sample_offset=int(rng.integers(0, 50)))
     kw["ids_sample"] = kw["sample_offset"] + int(rng.integers(0, spp))
     camera = dict(scenes.SPHERES_CAMERA) if name == "random_spheres" else {}
+    if name == "spheres_on_a_floor":
+        dist = float(10.0 ** rng.uniform(0.5, 2.0))
+        az, el = float(rng.uniform(0, 2 * np.pi)), float(rng.uniform(0.02, 1.5)) * float(rng.choice([-1.0, 1.0]))
+        camera = dict(lookfrom=(dist * np.cos(az) * np.cos(el), dist * np.sin(el), dist * np.sin(az) * np.cos(el)), lookat=(float(rng.uniform(-2, 2)), 0.0, float(rng.uniform(-1, 1))),
+                      vfov=float(np.degrees(2 * np.arctan(4.0 / dist))), background=(0.6, 0.7, 0.9))
     if rng.random() < 0.3:
         camera["defocus_angle"] = float(rng.choice([0.0, 2.0, 5.0]))
     if rng.random() < 0.15:
