@@ -184,7 +184,7 @@ typedef struct crt_stats {
     uint64_t rays;          /* path segments traced = world->hit() calls (camera.h:68)                      */
     uint64_t nodes;         /* nodes fetched (64-byte; 128-byte with CRT_BVH_WIDE=1)  (CRT_COUNT_WORK)      */
     uint64_t tri_tests;     /* 48-byte triangle records tested  (CRT_COUNT_WORK)                            */
-    uint64_t sphere_tests;  /* 32-byte sphere records tested    (CRT_COUNT_WORK)                            */
+    uint64_t sphere_tests;  /* 48-byte sphere records tested    (CRT_COUNT_WORK)                            */
     uint64_t tie_refolds;   /* rays that took the exact reference-order tie fold                            */
     uint64_t shaded_hits;   /* rays that hit something and were shaded (CRT_COUNT_WORK)                     */
     uint64_t sched[10];     /* schedule counters (CRT_COUNT_WORK): [0] shade-phase runs [1] lanes in them [2] longest wave
